@@ -1,0 +1,163 @@
+/* irbfn_hip.h -- C ABI of libirbfn_hip.so: the MI355X (gfx950) implementation of the IRBFN hot path.
+ *
+ * Each entry point names the reference interface (hzheng40/irbfn @ 2024_10_08, path:line) it replaces.
+ * Conventions
+ *   - every function returns an int status: 0 = IRBFN_OK, negative = irbfn_status below; nothing
+ *     throws or aborts across the ABI; irbfn_strerror() turns a status into text.
+ *   - `_dev` pointers are device (HBM) pointers owned by the caller; `_host` pointers are host memory
+ *     that is copied during the call.  The library never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work of a call is
+ *     enqueued on that stream; the call does not synchronise (no hipMalloc/hipFree/sync on the
+ *     launch path, so calls can be captured into a hipGraph once a descriptor exists).
+ *   - all floating point data is IEEE binary32, row-major, densely packed.
+ *   - NaN/Inf inputs propagate as IEEE arithmetic dictates (no clamping), like the reference.
+ */
+#ifndef IRBFN_HIP_H_
+#define IRBFN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRBFN_ABI_VERSION 1
+
+typedef enum irbfn_status {
+  IRBFN_OK = 0,
+  IRBFN_ERR_BAD_ARG = -1,       /* NULL pointer, negative size, unknown enum */
+  IRBFN_ERR_UNSUPPORTED = -2,   /* shape outside the compiled kernel set (see irbfn_net_create) */
+  IRBFN_ERR_HIP = -3,           /* a HIP runtime call failed; irbfn_last_hip_error() has the code */
+  IRBFN_ERR_NO_PARAMS = -4,     /* forward/vjp called before irbfn_net_set_params */
+  IRBFN_ERR_NO_DEVICE = -5      /* no gfx950 device visible */
+} irbfn_status;
+
+/* Radial basis functions of flax_rbf (deprecated/f1tenth_gym/examples/flax_rbf/flax_rbf/flax_rbf.py:34-111),
+ * selected in the reference by `basis_func: <name>` in the YAML model card (irbfn_planner.py:72). */
+typedef enum irbfn_basis {
+  IRBFN_GAUSSIAN = 0,             /* exp(-d^2)            flax_rbf.py:35-37 */
+  IRBFN_GAUSSIAN_WIDE = 1,        /* exp(-0.1 d^2)        :40-42 */
+  IRBFN_GAUSSIAN_WIDER = 2,       /* exp(-0.01 d^2)       :45-47 */
+  IRBFN_INVERSE_QUADRATIC = 3,    /* 1/(1+d^2)            :50-52 */
+  IRBFN_LINEAR = 4,               /* d                    :55-57 */
+  IRBFN_QUADRATIC = 5,            /* d^2                  :61-63 */
+  IRBFN_MULTIQUADRIC = 6,         /* sqrt(1+d^2)          :67-69 */
+  IRBFN_INVERSE_MULTIQUADRIC = 7, /* 1/sqrt(1+d^2)        :73-75 */
+  IRBFN_SPLINE = 8,               /* d^2 log(d+1)         :79-81 */
+  IRBFN_POISSON_ONE = 9,          /* (d-1) exp(-d)        :85-87 */
+  IRBFN_POISSON_TWO = 10,         /* ((d-2)/2) d exp(-d)  :91-97 */
+  IRBFN_MATERN32 = 11,            /* :101-103 */
+  IRBFN_MATERN52 = 12             /* :107-111 */
+} irbfn_basis;
+
+/* Roll-out models (one lane per trajectory). */
+typedef enum irbfn_rollout_mode {
+  IRBFN_ROLLOUT_ST_SELECT = 0, /* integrate_st_mult: scan of dynamic_st_onestep, select(V>3, f, f_ks)
+                                  src/irbfn_mpc/dynamics.py:9-100.        state 7, x0u[B,7+2T] -> [B,T,7] */
+  IRBFN_ROLLOUT_ST_KS = 1,     /* scan of the kinematic one-step map dynamic_st_onestep_aux
+                                  src/irbfn_mpc/dynamics.py:103-187 (T=1 is that function itself).
+                                                                          state 7, x0u[B,7+2T] -> [B,T,7] */
+  IRBFN_ROLLOUT_FULLINT = 2,   /* inline kinematic bicycle of train_step_fullint
+                                  scripts/train_nmpc.py:306-374.          state 5, x0u[B,1+2T]=[v0,u] -> [B,T,5] */
+  IRBFN_ROLLOUT_FRENET_LS = 3, /* integrate_frenet_mult (low-speed RHS)
+                                  src/irbfn_mpc/dynamics.py:190-290.      state 8, x0u[B,8+2T] -> [B,T,8] */
+  IRBFN_ROLLOUT_SPIRAL = 4     /* integrate_path_mult: cubic-spiral path, T = number of samples N
+                                  src/irbfn_mpc/planner_utils.py:8-77.    state 6, x0u[B,5]=(k0..k3,s) -> [B,N,6] */
+} irbfn_rollout_mode;
+
+/* ---------------------------------------------------------------------------------------------
+ * Network descriptor.  Replaces the Flax module object `WCRBFNet(**cfg)` (src/irbfn_mpc/model.py:98-167)
+ * plus the bound parameter pytree.  The static part is the YAML model card
+ * (scripts/train_nmpc.py:431-450): in_features D, out_features O, num_kernels K, num_regions R,
+ * basis_func, lower_bounds / upper_bounds / delta / dimension_ranges of the smooth region gate
+ * `_region_activation` (model.py:42-95).
+ *
+ *   lo_tab_host, hi_tab_host : [nsplit][max_ranges] -- row d holds lower_bounds[d][:] / upper_bounds[d][:]
+ *                              (ragged rows padded with anything; padding is never indexed)
+ *   delta_host               : [nsplit]
+ *   dim_ranges_host          : [n_ranges][nsplit] ints; regions r >= n_ranges have gamma = 0 (model.py:70)
+ *   nsplit = len(activation_idx) (model.py:128); the gate reads x[:, d] for d < nsplit (model.py:74-81).
+ *
+ * Compiled kernel set: D in 1..8; any O >= 1 (O is padded internally to a compiled width);
+ * R*K >= 1; nsplit <= 8.  Outside it: IRBFN_ERR_UNSUPPORTED.
+ * The descriptor owns device buffers for the packed centre records and the gate tables; it is
+ * immutable between irbfn_net_set_params calls and may be shared by host threads.
+ */
+typedef struct irbfn_net irbfn_net;
+
+int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis, int nsplit,
+                     int max_ranges, const float* lo_tab_host, const float* hi_tab_host,
+                     const float* delta_host, const int* dim_ranges_host, int n_ranges);
+int irbfn_net_destroy(irbfn_net* net);
+
+/* Binds the parameter pytree {"rbf_list": {"centers"[R,K,D], "log_sigs"[R,K]},
+ * "linear": {"kernel"[K,O], "bias"[O]}} (checkpoint layout).  Device pointers; the
+ * data is re-packed on `stream` into the descriptor's own record buffer (one tiny kernel), so the
+ * caller may overwrite its arrays afterwards.  Call again after every optimiser step. */
+int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* log_sigs_dev,
+                         const float* kernel_dev, const float* bias_dev, void* stream);
+
+/* Forward: replaces `WCRBFNet.apply(params, x)` (model.py:169-198; called as
+ * `state.apply_fn(state.params, x)` in pred_step, src/irbfn_mpc/irbfn_planner.py:29-32).
+ * x_dev[B,D] -> out_dev[B,O].  B = 0 is a no-op. */
+int irbfn_net_forward(irbfn_net* net, const float* x_dev, float* out_dev, int64_t B, void* stream);
+
+/* Region gate alone: `_region_activation` (model.py:42-95).  x_dev[B,D] -> gamma_dev[B,R]. */
+int irbfn_net_gate(irbfn_net* net, const float* x_dev, float* gamma_dev, int64_t B, void* stream);
+
+/* Bytes of scratch irbfn_net_vjp needs for batch B (caller allocates; may be reused across calls). */
+int64_t irbfn_net_vjp_workspace_bytes(const irbfn_net* net, int64_t B);
+
+/* Parameter VJP: replaces `jax.value_and_grad(loss_fn)(state.params)` restricted to the network
+ * (scripts/train_nmpc.py:297-298, scripts/train_nmpc_frenet.py:388-389,416-417).
+ * Cotangent gout_dev[B,O] -> g_centers[R,K,D], g_log_sigs[R,K], g_kernel[K,O], g_bias[O]
+ * (overwritten, not accumulated).  Gradients w.r.t. x are never taken by the reference and are
+ * not produced.  Deterministic (no float atomics). */
+int irbfn_net_vjp(irbfn_net* net, const float* x_dev, const float* gout_dev, float* g_centers_dev,
+                  float* g_log_sigs_dev, float* g_kernel_dev, float* g_bias_dev, int64_t B,
+                  void* workspace_dev, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Roll-outs.  Replace integrate_st_mult (dynamics.py:94-100), dynamic_st_onestep_aux (:103-187),
+ * integrate_frenet_mult (:284-290), the inline bicycle of train_step_fullint
+ * (scripts/train_nmpc.py:329-374) and integrate_path_mult (planner_utils.py:62-77).
+ * Control layout is the reference's column-major pairs u = [a_0..a_{T-1}, sv_0..sv_{T-1}]
+ * (dynamics.py:98: reshape(5, 2, order="F")); T is a run-time parameter (the reference hard-codes
+ * T = 5 and N = 9).  dyn_params_host[13] = [mu, m, I, lf, lr, C_Sf, C_Sr, h, dt, sv_max, a_max,
+ * s_max, v_max] (dynamics.py:24-36); ignored (may be NULL) for FULLINT and SPIRAL.
+ */
+int irbfn_rollout_state_dim(int mode);              /* 7, 7, 5, 8, 6 */
+int irbfn_rollout_input_dim(int mode, int T);       /* columns of x0u */
+int irbfn_rollout_forward(int mode, const float* x0u_dev, const float* dyn_params_host,
+                          float* states_dev, int64_t B, int T, void* stream);
+
+/* VJP of the roll-out w.r.t. its input row: gstates_dev[B,T,S] -> g_x0u_dev[B, input_dim].
+ * Replaces JAX's transpose of the scans under value_and_grad (scripts/train_nmpc.py:275-276,
+ * :356-374; scripts/train_nmpc_frenet.py:408-409; deprecated/train_newlut.py:194-199).
+ * clip() passes gradient 1 strictly inside its bounds, 0 strictly outside and `clip_tie` (0, 0.5 or
+ * 1) exactly on a bound.  ST_SELECT differentiates the selected branch only
+ * (finite where JAX's select would give NaN). */
+int irbfn_rollout_vjp(int mode, const float* x0u_dev, const float* dyn_params_host,
+                      const float* gstates_dev, float* g_x0u_dev, int64_t B, int T, float clip_tie,
+                      void* stream);
+
+/* Fused planning tick: net forward + roll-out in one launch, the predicted controls never leave
+ * the chip.  Batched form of IRBFNPlanner.plan's `pred_step` -> `hstack` -> `integrate_st_mult`
+ * (src/irbfn_mpc/irbfn_planner.py:205-212).  x_dev[B,D] queries, state0_dev[B,S] initial states,
+ * requires O = 2T.  controls_dev may be NULL (then only states are written). */
+int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, const float* state0_dev,
+                              const float* dyn_params_host, float* controls_dev, float* states_dev,
+                              int64_t B, int T, void* stream);
+
+/* Diagnostics */
+int irbfn_abi_version(void);
+int irbfn_device_count(void);
+int irbfn_last_hip_error(void);
+const char* irbfn_strerror(int status);
+/* Name + launch geometry of the kernel the last forward call on this net used (for bench/profiles). */
+int irbfn_net_last_launch(const irbfn_net* net, char* name_buf, int name_len, int* grid, int* block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRBFN_HIP_H_ */

@@ -1,0 +1,82 @@
+"""Builds libirbfn_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+``python -m irbfn_amd.build`` or ``irbfn_amd.build.build_lib()``.  hipcc cross-compiles without a
+GPU.  Objects are cached under ``irbfn_amd/csrc/_obj`` and rebuilt when a source or header is newer.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libirbfn_hip.so")
+ARCH = "gfx950"
+
+# (source, object name, extra flags)
+UNITS = [
+    ("abi.hip", "abi.o", []),
+    ("rbf_forward.hip", "rbf_forward.o", []),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d3.o", ["-DIRBFN_INST_D=3"]),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d4.o", ["-DIRBFN_INST_D=4"]),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d7.o", ["-DIRBFN_INST_D=7"]),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d8.o", ["-DIRBFN_INST_D=8"]),
+    ("rbf_vjp.hip", "rbf_vjp.o", []),
+    ("rollout.hip", "rollout.o", []),
+    ("rollout_vjp.hip", "rollout_vjp.o", []),
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _newest_header() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(INCLUDE, "irbfn_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(unit, hipcc, hdr_mtime, force):
+    src, obj, extra = unit
+    srcp, objp = os.path.join(CSRC, src), os.path.join(OBJ, obj)
+    if (not force and os.path.exists(objp)
+            and os.path.getmtime(objp) >= max(os.path.getmtime(srcp), hdr_mtime)):
+        return objp, False
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-I", INCLUDE, "-I", CSRC,
+           *extra, "-c", srcp, "-o", objp]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src} {extra}:\n{r.stderr[-4000:]}")
+    return objp, True
+
+
+def build_lib(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _newest_header()
+    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        res = list(ex.map(lambda u: _compile(u, hipcc, hdr, force), UNITS))
+    objs = [r[0] for r in res]
+    rebuilt = any(r[1] for r in res)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print(f"[irbfn_amd.build] {'rebuilt' if rebuilt else 'up to date'}: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,220 @@
+// extern "C" entry points of libirbfn_hip.so (declared in include/irbfn_hip.h).
+#include <new>
+#include <string.h>
+
+#include "common.h"
+
+namespace irbfn {
+thread_local int g_last_hip_error = 0;
+int padded_D(int D);
+}  // namespace irbfn
+
+using namespace irbfn;
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int irbfn_abi_version(void) { return IRBFN_ABI_VERSION; }
+
+int irbfn_last_hip_error(void) { return g_last_hip_error; }
+
+int irbfn_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return 0;
+  }
+  return n;
+}
+
+const char* irbfn_strerror(int status) {
+  switch (status) {
+    case IRBFN_OK: return "ok";
+    case IRBFN_ERR_BAD_ARG: return "bad argument (null pointer, negative size or unknown enum)";
+    case IRBFN_ERR_UNSUPPORTED: return "shape or mode outside the compiled kernel set";
+    case IRBFN_ERR_HIP: return "HIP runtime error (see irbfn_last_hip_error)";
+    case IRBFN_ERR_NO_PARAMS: return "irbfn_net_set_params has not been called";
+    case IRBFN_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis, int nsplit,
+                     int max_ranges, const float* lo_tab_host, const float* hi_tab_host,
+                     const float* delta_host, const int* dim_ranges_host, int n_ranges) {
+  if (!out_net) return IRBFN_ERR_BAD_ARG;
+  *out_net = nullptr;
+  if (D < 1 || R < 1 || K < 1 || O < 1 || nsplit < 0 || max_ranges < 0 || n_ranges < 0)
+    return IRBFN_ERR_BAD_ARG;
+  if (basis < IRBFN_GAUSSIAN || basis > IRBFN_MATERN52) return IRBFN_ERR_BAD_ARG;
+  if (nsplit > 0 && (!lo_tab_host || !hi_tab_host || !delta_host || max_ranges < 1)) return IRBFN_ERR_BAD_ARG;
+  if (n_ranges > 0 && nsplit > 0 && !dim_ranges_host) return IRBFN_ERR_BAD_ARG;
+  if (nsplit > D || nsplit > kMaxSplit) return IRBFN_ERR_UNSUPPORTED;
+  if ((long)R * K > (1L << 30)) return IRBFN_ERR_UNSUPPORTED;
+  const int DC = padded_D(D), OP = padded_O(O);
+  if (DC < 0 || OP < 0) return IRBFN_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_ranges * nsplit; ++i)
+    if (dim_ranges_host[i] < 0 || dim_ranges_host[i] >= max_ranges) return IRBFN_ERR_BAD_ARG;
+  if (n_ranges > R) n_ranges = R;   // jnp .at[:, i].set beyond num_regions is dropped (model.py:93)
+
+  irbfn_net* net = new (std::nothrow) irbfn_net();
+  if (!net) return IRBFN_ERR_BAD_ARG;
+  memset(net, 0, sizeof(*net));
+  net->D = D; net->R = R; net->K = K; net->O = O; net->basis = basis;
+  net->bclass = basis_class(basis);
+  net->DC = DC; net->OP = OP; net->N = R * K;
+  net->S = (DC + 1 + OP + 3) & ~3;
+  net->nsplit = nsplit; net->max_ranges = max_ranges > 0 ? max_ranges : 1; net->n_ranges = n_ranges;
+
+  const size_t tab = (size_t)(nsplit > 0 ? nsplit : 1) * net->max_ranges;
+  const size_t nr = (size_t)(n_ranges > 0 ? n_ranges : 1) * (nsplit > 0 ? nsplit : 1);
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 4);
+  };
+  alloc((void**)&net->rec, (size_t)net->N * net->S * sizeof(float));
+  alloc((void**)&net->bias, (size_t)OP * sizeof(float));
+  alloc((void**)&net->sig2, (size_t)net->N * sizeof(float));
+  alloc((void**)&net->gate_lo, tab * sizeof(float));
+  alloc((void**)&net->gate_hi, tab * sizeof(float));
+  alloc((void**)&net->gate_delta, (size_t)(nsplit > 0 ? nsplit : 1) * sizeof(float));
+  alloc((void**)&net->gate_ranges, nr * sizeof(int));
+  if (e == hipSuccess && nsplit > 0) {
+    e = hipMemcpy(net->gate_lo, lo_tab_host, tab * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(net->gate_hi, hi_tab_host, tab * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(net->gate_delta, delta_host, (size_t)nsplit * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_ranges > 0)
+      e = hipMemcpy(net->gate_ranges, dim_ranges_host, (size_t)n_ranges * nsplit * sizeof(int),
+                    hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    irbfn_net_destroy(net);
+    return IRBFN_ERR_HIP;
+  }
+  *out_net = net;
+  return IRBFN_OK;
+}
+
+int irbfn_net_destroy(irbfn_net* net) {
+  if (!net) return IRBFN_OK;
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete net;
+  return IRBFN_OK;
+}
+
+int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* log_sigs_dev,
+                         const float* kernel_dev, const float* bias_dev, void* stream) {
+  if (!net || !centers_dev || !log_sigs_dev || !kernel_dev || !bias_dev) return IRBFN_ERR_BAD_ARG;
+  int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
+  if (rc == IRBFN_OK) net->has_params = true;
+  return rc;
+}
+
+int irbfn_net_forward(irbfn_net* net, const float* x_dev, float* out_dev, int64_t B, void* stream) {
+  if (!net || B < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || !out_dev) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  return launch_forward(net, x_dev, out_dev, B, as_stream(stream));
+}
+
+int irbfn_net_gate(irbfn_net* net, const float* x_dev, float* gamma_dev, int64_t B, void* stream) {
+  if (!net || B < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || !gamma_dev) return IRBFN_ERR_BAD_ARG;
+  return launch_gate(net, x_dev, gamma_dev, B, as_stream(stream));
+}
+
+int64_t irbfn_net_vjp_workspace_bytes(const irbfn_net* net, int64_t B) {
+  if (!net || B < 0) return IRBFN_ERR_BAD_ARG;
+  return vjp_workspace_bytes(net, B);
+}
+
+int irbfn_net_vjp(irbfn_net* net, const float* x_dev, const float* gout_dev, float* g_centers_dev,
+                  float* g_log_sigs_dev, float* g_kernel_dev, float* g_bias_dev, int64_t B,
+                  void* workspace_dev, int64_t workspace_bytes, void* stream) {
+  if (!net || B < 0 || !g_centers_dev || !g_log_sigs_dev || !g_kernel_dev || !g_bias_dev)
+    return IRBFN_ERR_BAD_ARG;
+  if (B > 0 && (!x_dev || !gout_dev)) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  if (workspace_bytes < vjp_workspace_bytes(net, B) || (!workspace_dev && vjp_workspace_bytes(net, B) > 0))
+    return IRBFN_ERR_BAD_ARG;
+  return launch_vjp(net, x_dev, gout_dev, g_centers_dev, g_log_sigs_dev, g_kernel_dev, g_bias_dev, B,
+                    workspace_dev, workspace_bytes, as_stream(stream));
+}
+
+int irbfn_rollout_state_dim(int mode) {
+  const int s = rollout_state_dim(mode);
+  return s < 0 ? IRBFN_ERR_BAD_ARG : s;
+}
+
+int irbfn_rollout_input_dim(int mode, int T) {
+  if (T < 0) return IRBFN_ERR_BAD_ARG;
+  const int l = rollout_input_dim(mode, T);
+  return l < 0 ? IRBFN_ERR_BAD_ARG : l;
+}
+
+static int load_dyn(int mode, const float* dyn_params_host, DynParams* dp) {
+  memset(dp, 0, sizeof(*dp));
+  const bool needs = mode == IRBFN_ROLLOUT_ST_SELECT || mode == IRBFN_ROLLOUT_ST_KS ||
+                     mode == IRBFN_ROLLOUT_FRENET_LS;
+  if (needs && !dyn_params_host) return IRBFN_ERR_BAD_ARG;
+  if (dyn_params_host) memcpy(dp->p, dyn_params_host, sizeof(dp->p));
+  return IRBFN_OK;
+}
+
+int irbfn_rollout_forward(int mode, const float* x0u_dev, const float* dyn_params_host,
+                          float* states_dev, int64_t B, int T, void* stream) {
+  if (rollout_state_dim(mode) < 0 || B < 0 || T < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0 || T == 0) return IRBFN_OK;
+  if (!x0u_dev || !states_dev) return IRBFN_ERR_BAD_ARG;
+  DynParams dp;
+  int rc = load_dyn(mode, dyn_params_host, &dp);
+  if (rc != IRBFN_OK) return rc;
+  return launch_rollout_forward(mode, x0u_dev, dp, states_dev, B, T, as_stream(stream));
+}
+
+int irbfn_rollout_vjp(int mode, const float* x0u_dev, const float* dyn_params_host,
+                      const float* gstates_dev, float* g_x0u_dev, int64_t B, int T, float clip_tie,
+                      void* stream) {
+  if (rollout_state_dim(mode) < 0 || B < 0 || T < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x0u_dev || !g_x0u_dev || (T > 0 && !gstates_dev)) return IRBFN_ERR_BAD_ARG;
+  DynParams dp;
+  int rc = load_dyn(mode, dyn_params_host, &dp);
+  if (rc != IRBFN_OK) return rc;
+  return launch_rollout_vjp(mode, x0u_dev, dp, gstates_dev, g_x0u_dev, B, T, clip_tie, as_stream(stream));
+}
+
+int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, const float* state0_dev,
+                              const float* dyn_params_host, float* controls_dev, float* states_dev,
+                              int64_t B, int T, void* stream) {
+  if (!net || rollout_state_dim(mode) < 0 || B < 0 || T < 1) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || !state0_dev || !states_dev) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  DynParams dp;
+  int rc = load_dyn(mode, dyn_params_host, &dp);
+  if (rc != IRBFN_OK) return rc;
+  return launch_forward_rollout(net, mode, x_dev, state0_dev, dp, controls_dev, states_dev, B, T,
+                                as_stream(stream));
+}
+
+int irbfn_net_last_launch(const irbfn_net* net, char* name_buf, int name_len, int* grid, int* block) {
+  if (!net) return IRBFN_ERR_BAD_ARG;
+  if (name_buf && name_len > 0) {
+    strncpy(name_buf, net->last_name, (size_t)name_len - 1);
+    name_buf[name_len - 1] = 0;
+  }
+  if (grid) *grid = net->last_grid;
+  if (block) *block = net->last_block;
+  return IRBFN_OK;
+}
+
+}  // extern "C"

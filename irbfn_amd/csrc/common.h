@@ -1,0 +1,103 @@
+// Shared declarations of libirbfn_hip.so (gfx950 only; see include/irbfn_hip.h for the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "irbfn_hip.h"
+
+namespace irbfn {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kMaxSplit = 8;       // nsplit <= 8 (gate dims)
+constexpr int kMaxD = 8;
+
+// basis classes the hot loops are specialised on
+enum BasisClass : int { BC_GAUSS = 0, BC_IQ = 1, BC_IMQ = 2, BC_GENERIC = 3 };
+
+inline int basis_class(int basis) {
+  switch (basis) {
+    case IRBFN_GAUSSIAN:
+    case IRBFN_GAUSSIAN_WIDE:
+    case IRBFN_GAUSSIAN_WIDER: return BC_GAUSS;
+    case IRBFN_INVERSE_QUADRATIC: return BC_IQ;
+    case IRBFN_INVERSE_MULTIQUADRIC: return BC_IMQ;
+    default: return BC_GENERIC;
+  }
+}
+
+// Gaussian family exponent scale a in exp(-a d^2) (flax_rbf.py:35-47)
+inline float gauss_scale(int basis) {
+  return basis == IRBFN_GAUSSIAN_WIDE ? 0.1f : (basis == IRBFN_GAUSSIAN_WIDER ? 0.01f : 1.0f);
+}
+
+extern thread_local int g_last_hip_error;
+
+#define IRBFN_HIP_CHECK(expr)                         \
+  do {                                                \
+    hipError_t e__ = (expr);                          \
+    if (e__ != hipSuccess) {                          \
+      ::irbfn::g_last_hip_error = (int)e__;           \
+      return IRBFN_ERR_HIP;                           \
+    }                                                 \
+  } while (0)
+
+struct GateTables {        // device pointers owned by the descriptor
+  const float* lo;         // [nsplit][max_ranges]
+  const float* hi;         // [nsplit][max_ranges]
+  const float* delta;      // [nsplit]
+  const int* dim_ranges;   // [n_ranges][nsplit]
+  int nsplit, max_ranges, n_ranges;
+};
+
+struct DynParams {         // dynamics.py:24-36
+  float p[13];
+};
+
+}  // namespace irbfn
+
+// The descriptor behind the opaque handle of the ABI.
+struct irbfn_net {
+  int D, R, K, O, basis, bclass;
+  int DC;       // D padded to a compiled width (padding coordinates are 0 in x and c)
+  int N;        // R*K centres
+  int OP;       // O padded to a compiled accumulator width
+  int S;        // floats per packed centre record: c[D], scale, W[OP], padded to a multiple of 4
+  float* rec;   // [N][S]   packed records (device)
+  float* bias;  // [OP]     (device, zero padded)
+  float* sig2;  // [N]      exp(-2 log_sig) (device) -- VJP
+  // raw parameter pointers are NOT kept: set_params copies what it needs
+  float* gate_lo;
+  float* gate_hi;
+  float* gate_delta;
+  int* gate_ranges;
+  int nsplit, max_ranges, n_ranges;
+  bool has_params;
+  char last_name[96];
+  int last_grid, last_block;
+
+  irbfn::GateTables gate() const {
+    return irbfn::GateTables{gate_lo, gate_hi, gate_delta, gate_ranges, nsplit, max_ranges, n_ranges};
+  }
+};
+
+namespace irbfn {
+// launchers implemented per translation unit
+int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
+                const float* bias, hipStream_t s);
+int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
+int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStream_t s);
+int64_t vjp_workspace_bytes(const irbfn_net* net, int64_t B);
+int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_centers, float* g_log_sigs,
+               float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s);
+int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, float* states, int64_t B,
+                           int T, hipStream_t s);
+int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const float* gstates,
+                       float* g_x0u, int64_t B, int T, float clip_tie, hipStream_t s);
+int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float* state0,
+                           const DynParams& dp, float* controls, float* states, int64_t B, int T,
+                           hipStream_t s);
+int padded_O(int O);
+int rollout_state_dim(int mode);
+int rollout_input_dim(int mode, int T);
+}  // namespace irbfn

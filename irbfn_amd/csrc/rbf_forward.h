@@ -1,0 +1,76 @@
+// K1: fused WCRBFNet forward for gfx950.
+//
+// Replaces WCRBFNet.__call__ (src/irbfn_mpc/model.py:169-198) = region gate (model.py:42-95) +
+// vmapped RBFLayer (flax_rbf.py:258-285) + gamma-weighted sum over regions (model.py:193) + Dense
+// (model.py:196), in ONE launch, with no [B,R,K] or [B,K] intermediate in HBM.
+//
+// Mapping ("query-lane"): one lane owns Q queries (x and the Q*OP output accumulators live in
+// VGPRs); the NW waves of a workgroup share the same 64*Q queries and split the N = R*K centres
+// among themselves.  Everything that depends on the centre only -- c[D], the folded width scale and
+// the weight row W[k,:] -- is wave-uniform, so the packed centre records stream through the SCALAR
+// cache into SGPRs (s_load_dwordxN) and feed the VALU as the one SGPR operand a gfx9 VALU
+// instruction may carry: no LDS traffic, no per-lane loads in the hot loop.  Per (query, centre)
+// pair: D v_sub + D v_fma (distance), 1 v_mul, 1 transcendental (v_exp / v_rcp / v_rsq), OP v_fma.
+// The NW partial sums are combined through LDS in a fixed order (deterministic), gamma and bias
+// are applied and the tile is written with coalesced stores.
+#pragma once
+
+#include "common.h"
+
+namespace irbfn {
+
+struct FwdArgs {
+  const float* __restrict__ x;     // [B][Dreal]
+  const float* __restrict__ rec;   // [N][S]
+  const float* __restrict__ bias;  // [OP]
+  float* __restrict__ out;         // [B][O]
+  GateTables gate;
+  long B;
+  int Dreal, O, N, K, S, basis;
+  // fused roll-out (forward_rollout only)
+  const float* __restrict__ state0;
+  float* __restrict__ states;
+  int T, mode;
+  DynParams dp;
+};
+
+__device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float fast_rsq(float v) { return __builtin_amdgcn_rsqf(v); }
+
+// phi from the squared distance r2 and the record's folded scale sc.
+//   BC_GAUSS : sc = -a*log2(e)*exp(-2 log_sig)  -> phi = 2^(r2*sc) = exp(-a d^2)   (flax_rbf.py:35-47)
+//   others   : sc = exp(-2 log_sig)             -> d^2 = r2*sc
+template <int BC>
+__device__ __forceinline__ float basis_from_r2(float r2, float sc, int basis) {
+  const float t = r2 * sc;
+  if constexpr (BC == BC_GAUSS) {
+    return fast_exp2(t);
+  } else if constexpr (BC == BC_IQ) {
+    return fast_rcp(1.0f + t);                 // flax_rbf.py:50-52
+  } else if constexpr (BC == BC_IMQ) {
+    return fast_rsq(1.0f + t);                 // flax_rbf.py:73-75
+  } else {
+    const float d2 = t;
+    const float d = sqrtf(d2);                 // flax_rbf.py:280
+    switch (basis) {
+      case IRBFN_LINEAR: return d;                                         // :55-57
+      case IRBFN_QUADRATIC: return d2;                                     // :61-63
+      case IRBFN_MULTIQUADRIC: return sqrtf(1.0f + d2);                    // :67-69
+      case IRBFN_SPLINE: return d2 * logf(d + 1.0f);                       // :79-81
+      case IRBFN_POISSON_ONE: return (d - 1.0f) * expf(-d);                // :85-87
+      case IRBFN_POISSON_TWO: return ((d - 2.0f) / 2.0f) * d * expf(-d);   // :91-97
+      case IRBFN_MATERN32: return (1.0f + 1.7320508075688772f * d) * expf(-1.7320508075688772f * d);
+      case IRBFN_MATERN52:
+        return (1.0f + 2.23606797749979f * d + (5.0f / 3.0f) * d2) * expf(-2.23606797749979f * d);
+      default: return 0.0f;
+    }
+  }
+}
+
+// one factor of the smooth indicator: ((tanh(delta*(x-lo))+1)/2) * ((tanh(delta*(hi-x))+1)/2), model.py:83-85
+__device__ __forceinline__ float gate_factor(float xv, float lo, float hi, float delta) {
+  return ((tanhf(delta * (xv - lo)) + 1.0f) * 0.5f) * ((tanhf(delta * (hi - xv)) + 1.0f) * 0.5f);
+}
+
+}  // namespace irbfn

@@ -1,0 +1,215 @@
+// K0 (pack), gate kernel and the K1 dispatcher -- see rbf_forward.h for the design of K1; the K1
+// instantiations live in rbf_forward_kernels.hip (one object per compiled D).
+#include "rbf_forward.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace irbfn {
+
+int launch_forward_d3(const FwdArgs&, int, int, int, bool, bool, int, size_t, hipStream_t, int*);
+int launch_forward_d4(const FwdArgs&, int, int, int, bool, bool, int, size_t, hipStream_t, int*);
+int launch_forward_d7(const FwdArgs&, int, int, int, bool, bool, int, size_t, hipStream_t, int*);
+int launch_forward_d8(const FwdArgs&, int, int, int, bool, bool, int, size_t, hipStream_t, int*);
+
+static const int kCompiledOP[] = {2, 4, 5, 8, 10, 16, 32, 64, 100, 128};
+
+int padded_O(int O) {
+  for (int op : kCompiledOP)
+    if (O <= op) return op;
+  return -1;
+}
+
+int padded_D(int D) {
+  if (D <= 3) return 3;
+  if (D == 4) return 4;
+  if (D <= 7) return 7;
+  if (D == 8) return 8;
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: pack the parameter pytree into per-centre records  rec[n] = { c[0..DC), scale, W[k][0..OP) }.
+// n = r*K + k; the weight row is replicated per region so that the hot loop reads ONE contiguous
+// scalar stream.  Runs once per irbfn_net_set_params (N*S floats, 0.33 MB at cfg-2).
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_records_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
+                                    const float* __restrict__ kernel, const float* __restrict__ bias,
+                                    float* __restrict__ rec, float* __restrict__ bias_out,
+                                    float* __restrict__ sig2, int N, int K, int D, int DC, int O, int OP,
+                                    int S, int bclass, float gscale) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < OP) bias_out[n] = n < O ? bias[n] : 0.0f;
+  if (n >= N) return;
+  const int k = n % K;
+  float* r = rec + (size_t)n * S;
+  for (int j = 0; j < DC; ++j) r[j] = j < D ? centers[(size_t)n * D + j] : 0.0f;
+  const float s2 = expf(-2.0f * log_sigs[n]);          // 1/sigma^2, sigma = exp(log_sig) (flax_rbf.py:280)
+  sig2[n] = s2;
+  r[DC] = bclass == BC_GAUSS ? -gscale * 1.4426950408889634f * s2 : s2;
+  for (int o = 0; o < OP; ++o) r[DC + 1 + o] = o < O ? kernel[(size_t)k * O + o] : 0.0f;
+  for (int j = DC + 1 + OP; j < S; ++j) r[j] = 0.0f;
+}
+
+int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
+                const float* bias, hipStream_t s) {
+  const int n = net->N > net->OP ? net->N : net->OP;
+  const int block = 256;
+  const int grid = (n + block - 1) / block;
+  hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(block), 0, s, centers, log_sigs, kernel, bias,
+                     net->rec, net->bias, net->sig2, net->N, net->K, net->D, net->DC, net->O, net->OP,
+                     net->S, net->bclass, gauss_scale(net->basis));
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate kernel: _region_activation (model.py:42-95) -> gamma[B][R].  One wave per 64 queries; the
+// per-dimension factors are tabulated in LDS once, then every region is a product of nsplit
+// look-ups.  Used by irbfn_net_gate and as the pre-pass of the VJP.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gate_kernel(const float* __restrict__ x, float* __restrict__ gamma,
+                                                  GateTables gt, long B, int D, int R) {
+  extern __shared__ float gtab[];                 // [E][64]
+  const int lane = threadIdx.x;
+  const long b = (long)blockIdx.x * kWave + lane;
+  const long bb = b < B ? b : B - 1;
+  const int E = gt.nsplit * gt.max_ranges;
+  for (int e = 0; e < E; ++e) {
+    const int d = e / gt.max_ranges;
+    gtab[e * kWave + lane] = gate_factor(x[bb * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+  }
+  // each lane only reads its own column: no barrier needed
+  if (b >= B) return;
+  for (int r = 0; r < R; ++r) {
+    float g = 0.0f;
+    if (r < gt.n_ranges) {
+      g = 1.0f;
+      for (int d = 0; d < gt.nsplit; ++d)
+        g *= gtab[(d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d]) * kWave + lane];
+    }
+    gamma[b * R + r] = g;
+  }
+}
+
+int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  const size_t lds = (size_t)net->nsplit * net->max_ranges * kWave * sizeof(float);
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  const long grid = (B + kWave - 1) / kWave;
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)grid), dim3(kWave), lds, s, x, gamma, net->gate(), (long)B,
+                     net->D, net->R);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 dispatcher: picks queries-per-lane Q and waves-per-workgroup NW, sizes LDS, launches.
+// ------------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+static int pow2_floor(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
+}
+
+static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
+  const int OP = net->OP;
+  const bool gated = net->R > 1;
+  // --- Q: two queries per lane halve the scalar-stream traffic per pair; only with enough tiles
+  int Q = 1;
+  const bool q2_compiled = (OP == 2 || OP == 5 || OP == 10);
+  if (q2_compiled && a.B >= 2 * kWave * 512) Q = 2;
+  Q = env_int("IRBFN_FWD_Q", Q);
+  if (Q != 1 && !(Q == 2 && q2_compiled)) Q = 1;
+  const int ROWS = kWave * Q;
+  const long tiles = (a.B + ROWS - 1) / ROWS;
+  // --- NW: enough waves to cover the chip (1024 SIMDs) several times, >= 32 centres per wave
+  const int max_threads = (OP * Q > 48) ? 512 : 1024;
+  long want = (8192 + tiles - 1) / tiles;
+  int nw = want < 1 ? 1 : (want > 16 ? 16 : (int)want);
+  nw = pow2_floor(nw);
+  while (nw > 1 && net->N / nw < 32) nw /= 2;
+  while (nw * kWave > max_threads) nw /= 2;
+  nw = env_int("IRBFN_FWD_NW", nw);
+  if (nw < 1) nw = 1;
+  if (nw * kWave > max_threads) nw = max_threads / kWave;
+  // --- LDS: max(stage, gate table) aliased with the reduction buffers
+  const int OC = OP < 16 ? OP : 16;
+  size_t stage = (size_t)ROWS * net->D;
+  if (gated) stage += (size_t)net->nsplit * net->max_ranges * ROWS;
+  size_t red = (size_t)nw * Q * OC * (kWave + 1) + ROWS;
+  if (roll) red += (size_t)ROWS * net->O;
+  size_t lds = (stage > red ? stage : red) * sizeof(float);
+  while (lds > 160 * 1024 && nw > 1) {
+    nw /= 2;
+    red = (size_t)nw * Q * OC * (kWave + 1) + ROWS + (roll ? (size_t)ROWS * net->O : 0);
+    lds = (stage > red ? stage : red) * sizeof(float);
+  }
+  if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
+
+  int grid = 0, rc;
+  switch (net->DC) {
+    case 3: rc = launch_forward_d3(a, OP, Q, net->bclass, gated, roll, nw, lds, s, &grid); break;
+    case 4: rc = launch_forward_d4(a, OP, Q, net->bclass, gated, roll, nw, lds, s, &grid); break;
+    case 7: rc = launch_forward_d7(a, OP, Q, net->bclass, gated, roll, nw, lds, s, &grid); break;
+    case 8: rc = launch_forward_d8(a, OP, Q, net->bclass, gated, roll, nw, lds, s, &grid); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_qlane<D=%d,OP=%d,Q=%d,BC=%d,GATED=%d,ROLL=%d>",
+             net->DC, OP, Q, net->bclass, (int)gated, (int)roll);
+    net->last_grid = grid;
+    net->last_block = nw * kWave;
+  }
+  return rc;
+}
+
+static void fill_args(irbfn_net* net, FwdArgs& a, const float* x, float* out, int64_t B) {
+  memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.rec = net->rec;
+  a.bias = net->bias;
+  a.out = out;
+  a.gate = net->gate();
+  a.B = (long)B;
+  a.Dreal = net->D;
+  a.O = net->O;
+  a.N = net->N;
+  a.K = net->K;
+  a.S = net->S;
+  a.basis = net->basis;
+}
+
+int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  FwdArgs a;
+  fill_args(net, a, x, out, B);
+  return run_forward(net, a, false, s);
+}
+
+int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float* state0,
+                           const DynParams& dp, float* controls, float* states, int64_t B, int T,
+                           hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  if (mode != IRBFN_ROLLOUT_ST_SELECT && mode != IRBFN_ROLLOUT_ST_KS && mode != IRBFN_ROLLOUT_FULLINT &&
+      mode != IRBFN_ROLLOUT_FRENET_LS)
+    return IRBFN_ERR_UNSUPPORTED;
+  if (net->O != 2 * T) return IRBFN_ERR_BAD_ARG;
+  if (net->bclass == BC_GENERIC) return IRBFN_ERR_UNSUPPORTED;
+  FwdArgs a;
+  fill_args(net, a, x, controls, B);
+  a.state0 = state0;
+  a.states = states;
+  a.T = T;
+  a.mode = mode;
+  a.dp = dp;
+  return run_forward(net, a, true, s);
+}
+
+}  // namespace irbfn

@@ -1,0 +1,330 @@
+// K2: parameter VJP of the WCRBFNet forward (hand-derived).
+//
+// Replaces jax.value_and_grad(loss_fn)(state.params) restricted to the network
+// (scripts/train_nmpc.py:297-298, scripts/train_nmpc_frenet.py:388-389,416-417): given the
+// cotangent g[B,O] of `out`, produce d/d{centers, log_sigs, kernel, bias}.
+//
+//   hbar[b,k]  = sum_o g[b,o] W[k,o]                      G[b,r,k] = hbar[b,k] * gamma[b,r]
+//   d centers[r,k,:] = sum_b G * phi'(d2) * sig^-2 * (-2)(x_b - c_rk)
+//   d log_sigs[r,k]  = sum_b G * phi'(d2) * (-2 d2)
+//   d kernel[k,o]    = sum_b sum_r gamma[b,r] phi[b,r,k] g[b,o]         d bias[o] = sum_b g[b,o]
+//
+// Mapping ("centre-stationary"): one LANE owns one centre n = r*K + k: c, sigma^-2, W[k,:] and the
+// D+1+O gradient accumulators stay in VGPRs; the queries (x_b, g_b, gamma_b) are wave-uniform and
+// stream through the scalar cache into SGPRs.  A workgroup = 4 waves on the same 64 centres and
+// different query sub-slices; grid = centre groups x query slices.  Partial sums are combined
+// without atomics: LDS across the 4 waves, a [slice][value][centre] slab in the workspace, then a
+// fixed-order reduce kernel -> bitwise reproducible gradients.
+#include "rbf_forward.h"
+
+namespace irbfn {
+
+struct VjpArgs {
+  const float* __restrict__ x;      // [B][Dreal]
+  const float* __restrict__ g;      // [B][O]
+  const float* __restrict__ gamma;  // [B][R]
+  const float* __restrict__ rec;    // [N][S]
+  const float* __restrict__ sig2;   // [N]
+  float* __restrict__ part;         // [QSB][V][Npad]
+  long B;
+  int Dreal, O, N, K, R, S, basis, Npad, per_wave;
+  float gscale;
+};
+
+// d phi / d(d2) from phi (and d2) for the d2-only bases
+template <int BC>
+__device__ __forceinline__ float dphi_dd2(float phi, float gscale, int basis) {
+  if constexpr (BC == BC_GAUSS) return -gscale * phi;          // exp(-a d2)
+  else if constexpr (BC == BC_IQ) return -(phi * phi);         // 1/(1+d2)
+  else if constexpr (BC == BC_IMQ) return -0.5f * phi * phi * phi;   // (1+d2)^-1/2
+  else return basis == IRBFN_MULTIQUADRIC ? 0.5f / phi : 1.0f;       // sqrt(1+d2) | d2
+}
+
+template <int D, int OP, int BC, bool GATED>
+__global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
+  extern __shared__ float lds[];
+  constexpr int V = D + 1 + OP;
+  constexpr int LP = kWave + 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x * kWave + lane;
+  const int nn = n < a.N ? n : a.N - 1;
+  const int Dr = a.Dreal, O = a.O;
+
+  // this lane's centre
+  const float* rp = a.rec + (size_t)nn * a.S;
+  float c[D], w[OP];
+#pragma unroll
+  for (int j = 0; j < D; ++j) c[j] = rp[j];
+  const float sc = rp[D];
+  const float s2 = a.sig2[nn];
+#pragma unroll
+  for (int o = 0; o < OP; ++o) w[o] = rp[D + 1 + o];
+  const int r = nn / a.K;
+
+  float gc[D], gw[OP], gls = 0.0f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) gc[j] = 0.0f;
+#pragma unroll
+  for (int o = 0; o < OP; ++o) gw[o] = 0.0f;
+
+  // this wave's query slice
+  const long slice = (long)blockIdx.y * 4 + wave;
+  const long b0 = slice * a.per_wave;
+  long b1 = b0 + a.per_wave;
+  b1 = b1 < a.B ? b1 : a.B;
+  for (long b = b0; b < b1; ++b) {
+    const float* xb = a.x + b * Dr;          // uniform -> SGPRs
+    const float* gb = a.g + b * O;
+    float diff[D];
+    float r2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float xv = j < Dr ? xb[j < Dr ? j : 0] : 0.0f;
+      diff[j] = xv - c[j];
+      r2 = __builtin_fmaf(diff[j], diff[j], r2);
+    }
+    const float d2 = r2 * s2;
+    float phi;
+    if constexpr (BC == BC_GAUSS) phi = fast_exp2(r2 * sc);
+    else phi = basis_from_r2<BC>(r2, sc, a.basis);
+    float gam;
+    if constexpr (GATED) gam = a.gamma[b * a.R + r];
+    else gam = a.gamma[b];
+    float hbar = 0.0f;
+#pragma unroll
+    for (int o = 0; o < OP; ++o) {
+      const float go = o < O ? gb[o < O ? o : 0] : 0.0f;
+      hbar = __builtin_fmaf(go, w[o], hbar);
+      gw[o] = __builtin_fmaf(gam * phi, go, gw[o]);
+    }
+    const float t = hbar * gam * dphi_dd2<BC>(phi, a.gscale, a.basis);
+    gls = __builtin_fmaf(t, -2.0f * d2, gls);
+    const float coef = -2.0f * t * s2;
+#pragma unroll
+    for (int j = 0; j < D; ++j) gc[j] = __builtin_fmaf(coef, diff[j], gc[j]);
+  }
+
+  // combine the 4 waves through LDS (fixed order), write the slab row of this block
+  float* red = lds;                            // [4][V][LP]
+#pragma unroll
+  for (int j = 0; j < D; ++j) red[(wave * V + j) * LP + lane] = gc[j];
+  red[(wave * V + D) * LP + lane] = gls;
+#pragma unroll
+  for (int o = 0; o < OP; ++o) red[(wave * V + D + 1 + o) * LP + lane] = gw[o];
+  __syncthreads();
+  float* dst = a.part + (size_t)blockIdx.y * V * a.Npad + (size_t)blockIdx.x * kWave;
+  for (int idx = tid; idx < V * kWave; idx += 256) {
+    const int v = idx >> 6, l = idx & (kWave - 1);
+    const float s = (red[(0 * V + v) * LP + l] + red[(1 * V + v) * LP + l]) +
+                    (red[(2 * V + v) * LP + l] + red[(3 * V + v) * LP + l]);
+    dst[(size_t)v * a.Npad + l] = s;
+  }
+}
+
+// reduce the slabs over query slices (and, for d kernel, over regions); one thread per output value
+__global__ void vjp_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_centers,
+                                  float* __restrict__ g_log_sigs, float* __restrict__ g_kernel, int QSB,
+                                  int V, int Npad, int N, int K, int R, int D, int DC, int O) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_c = (long)N * D, n_l = N, n_k = (long)K * O;
+  if (i < n_c) {
+    const int n = (int)(i / D), j = (int)(i - (long)n * D);
+    float s = 0.0f;
+    for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + j) * Npad + n];
+    g_centers[i] = s;
+  } else if (i < n_c + n_l) {
+    const int n = (int)(i - n_c);
+    float s = 0.0f;
+    for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + DC) * Npad + n];
+    g_log_sigs[n] = s;
+  } else if (i < n_c + n_l + n_k) {
+    const long t = i - n_c - n_l;
+    const int k = (int)(t / O), o = (int)(t - (long)k * O);
+    float s = 0.0f;
+    for (int r = 0; r < R; ++r)
+      for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + DC + 1 + o) * Npad + (size_t)r * K + k];
+    g_kernel[t] = s;
+  }
+}
+
+// d bias[o] = sum_b g[b,o]: per-block column sums, then one block finishes (fixed order)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, float* __restrict__ part,
+                                                              long B, int O, long rows_per_block) {
+  extern __shared__ float sm[];                // [256]
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  r1 = r1 < B ? r1 : B;
+  const long total = (r1 - r0) * O;
+  const float* base = g + r0 * O;
+  // thread t sums flat indices i = t + k*stride with stride a multiple of O -> fixed column per thread
+  const int per = 256 / O > 0 ? 256 / O : 1;   // rows covered per sweep when O <= 256
+  if (O <= 256) {
+    const int stride = per * O;
+    const int t = threadIdx.x;
+    float s = 0.0f;
+    if (t < stride)
+      for (long i = t; i < total; i += stride) s += base[i];
+    sm[t] = t < stride ? s : 0.0f;
+    __syncthreads();
+    if (t < O) {
+      float acc = 0.0f;
+      for (int p = 0; p < per; ++p) acc += sm[p * O + t];
+      part[(size_t)blockIdx.x * O + t] = acc;
+    }
+  } else {
+    for (int o = threadIdx.x; o < O; o += 256) {
+      float s = 0.0f;
+      for (long rr = 0; rr < r1 - r0; ++rr) s += base[rr * O + o];
+      part[(size_t)blockIdx.x * O + o] = s;
+    }
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ g_bias, int nblocks, int O) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= O) return;
+  float s = 0.0f;
+  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * O + o];
+  g_bias[o] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct VjpPlan {
+  int groups, QSB, per_wave, Npad, V, bias_blocks;
+  long rows_per_block;
+  size_t off_gamma, off_part, off_bias, total;
+};
+
+static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
+  VjpPlan p;
+  p.groups = (net->N + kWave - 1) / kWave;
+  p.Npad = p.groups * kWave;
+  p.V = net->DC + 1 + net->OP;
+  long qsb = (8192 + (long)p.groups * 4 - 1) / ((long)p.groups * 4);
+  long max_qsb = (B + 4 * 64 - 1) / (4 * 64);       // >= 64 queries per wave
+  if (max_qsb < 1) max_qsb = 1;
+  if (qsb > max_qsb) qsb = max_qsb;
+  if (qsb < 1) qsb = 1;
+  if (qsb > 4096) qsb = 4096;
+  p.QSB = (int)qsb;
+  const long slices = qsb * 4;
+  p.per_wave = (int)((B + slices - 1) / slices);
+  if (p.per_wave < 1) p.per_wave = 1;
+  p.bias_blocks = (int)(B < 256 * 64 ? (B + 63) / 64 : 256);
+  if (p.bias_blocks < 1) p.bias_blocks = 1;
+  p.rows_per_block = (B + p.bias_blocks - 1) / p.bias_blocks;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  p.off_gamma = off; off += al((size_t)B * net->R * sizeof(float));
+  p.off_part = off;  off += al((size_t)p.QSB * p.V * p.Npad * sizeof(float));
+  p.off_bias = off;  off += al((size_t)p.bias_blocks * net->O * sizeof(float));
+  p.total = off;
+  return p;
+}
+
+int64_t vjp_workspace_bytes(const irbfn_net* net, int64_t B) {
+  if (B <= 0) return 0;
+  return (int64_t)make_plan(net, B).total;
+}
+
+template <int D, int OP>
+static int launch_vjp_bc(const VjpArgs& a, int bc, bool gated, dim3 grid, hipStream_t s) {
+  constexpr int V = D + 1 + OP;
+  const size_t lds = (size_t)4 * V * (kWave + 1) * sizeof(float);
+#define IRBFN_VCASE(BCV)                                                                                  \
+  case BCV: {                                                                                             \
+    if (gated) {                                                                                          \
+      auto k = rbf_vjp_kernel<D, OP, BCV, true>;                                                          \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                  \
+    } else {                                                                                              \
+      auto k = rbf_vjp_kernel<D, OP, BCV, false>;                                                         \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                  \
+    }                                                                                                     \
+    break;                                                                                                \
+  }
+  switch (bc) {
+    IRBFN_VCASE(BC_GAUSS)
+    IRBFN_VCASE(BC_IQ)
+    IRBFN_VCASE(BC_IMQ)
+    IRBFN_VCASE(BC_GENERIC)
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+#undef IRBFN_VCASE
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int D>
+static int launch_vjp_d(const VjpArgs& a, int OP, int bc, bool gated, dim3 grid, hipStream_t s) {
+  switch (OP) {
+    case 2: return launch_vjp_bc<D, 2>(a, bc, gated, grid, s);
+    case 4: return launch_vjp_bc<D, 4>(a, bc, gated, grid, s);
+    case 5: return launch_vjp_bc<D, 5>(a, bc, gated, grid, s);
+    case 8: return launch_vjp_bc<D, 8>(a, bc, gated, grid, s);
+    case 10: return launch_vjp_bc<D, 10>(a, bc, gated, grid, s);
+    case 16: return launch_vjp_bc<D, 16>(a, bc, gated, grid, s);
+    case 32: return launch_vjp_bc<D, 32>(a, bc, gated, grid, s);
+    case 64: return launch_vjp_bc<D, 64>(a, bc, gated, grid, s);
+    case 100: return launch_vjp_bc<D, 100>(a, bc, gated, grid, s);
+    case 128: return launch_vjp_bc<D, 128>(a, bc, gated, grid, s);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_centers, float* g_log_sigs,
+               float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s) {
+  (void)ws_bytes;
+  if (net->bclass == BC_GENERIC && net->basis != IRBFN_MULTIQUADRIC && net->basis != IRBFN_QUADRATIC)
+    return IRBFN_ERR_UNSUPPORTED;   // hand VJP exists for the d^2-only bases
+  const long n_c = (long)net->N * net->D, n_l = net->N, n_k = (long)net->K * net->O;
+  if (B == 0) {
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_centers, 0, n_c * sizeof(float), s));
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_log_sigs, 0, n_l * sizeof(float), s));
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_kernel, 0, n_k * sizeof(float), s));
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_bias, 0, (size_t)net->O * sizeof(float), s));
+    return IRBFN_OK;
+  }
+  const VjpPlan p = make_plan(net, B);
+  char* base = static_cast<char*>(ws);
+  float* gamma = reinterpret_cast<float*>(base + p.off_gamma);
+  float* part = reinterpret_cast<float*>(base + p.off_part);
+  float* bpart = reinterpret_cast<float*>(base + p.off_bias);
+
+  int rc = launch_gate(net, x, gamma, B, s);      // gamma[B][R] (model.py:42-95)
+  if (rc != IRBFN_OK) return rc;
+
+  VjpArgs a;
+  a.x = x; a.g = gout; a.gamma = gamma; a.rec = net->rec; a.sig2 = net->sig2; a.part = part;
+  a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.N = net->N; a.K = net->K; a.R = net->R; a.S = net->S;
+  a.basis = net->basis; a.Npad = p.Npad; a.per_wave = p.per_wave; a.gscale = gauss_scale(net->basis);
+  const dim3 grid(p.groups, p.QSB);
+  const bool gated = net->R > 1;
+  switch (net->DC) {
+    case 3: rc = launch_vjp_d<3>(a, net->OP, net->bclass, gated, grid, s); break;
+    case 4: rc = launch_vjp_d<4>(a, net->OP, net->bclass, gated, grid, s); break;
+    case 7: rc = launch_vjp_d<7>(a, net->OP, net->bclass, gated, grid, s); break;
+    case 8: rc = launch_vjp_d<8>(a, net->OP, net->bclass, gated, grid, s); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc != IRBFN_OK) return rc;
+
+  const long total = n_c + n_l + n_k;
+  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, g_centers,
+                     g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
+                     (long)B, net->O, p.rows_per_block);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((net->O + 63) / 64), dim3(64), 0, s, bpart, g_bias, p.bias_blocks,
+                     net->O);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+}  // namespace irbfn

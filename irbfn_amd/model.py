@@ -1,0 +1,289 @@
+"""``WCRBFNet`` -- host-side mirror of the reference's Flax module (src/irbfn_mpc/model.py:98-198).
+
+Same constructor fields as the reference / its YAML model card, same call surface
+``WCRBFNet(**cfg).apply(params, x)`` with the same parameter pytree
+``{"params": {"rbf_list": {"centers"[R,K,D], "log_sigs"[R,K]}, "linear": {"kernel"[K,O], "bias"[O]}}}``
+(checkpoint layout).  The arithmetic runs in the HIP kernels behind ``libirbfn_hip.so``; torch is
+used only for device memory and streams.  No CPU path: without the library or a GPU, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .flax_rbf import basis_name
+
+_CFG_FIELDS = ("in_features", "out_features", "num_kernels", "basis_func", "num_regions", "lower_bounds",
+               "upper_bounds", "dimension_ranges", "activation_idx", "delta")
+
+
+def _inner(params: dict) -> dict:
+    return params["params"] if "params" in params else params
+
+
+def _ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(torch) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device_f32(a, torch, device=None):
+    """numpy / torch (any float dtype, any device) -> contiguous float32 cuda tensor (no copy if already so)."""
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)     # float64 checkpoints are cast on load
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if t.device != dev:
+        t = t.to(dev)
+    return t.contiguous()
+
+
+def like_input(out_t, ref, torch):
+    """Give the result the flavour of the caller's input: numpy in -> numpy out, torch-cpu -> torch-cpu."""
+    if isinstance(ref, torch.Tensor):
+        return out_t if ref.is_cuda else out_t.cpu()
+    return out_t.cpu().numpy()
+
+
+class WCRBFNet:
+    """Interpolating RBF network (smooth region gate, R vmapped RBF layers, Dense).
+
+    Fields as in src/irbfn_mpc/model.py:112-125.  ``centers`` / ``fixed_centers`` / ``fixed_width``
+    select upstream-only layer classes whose source is not in the reference snapshot
+    (model.py:131-140); they all share the forward arithmetic of ``RBFLayer`` and differ in which
+    parameters train, so they are accepted and ignored for ``apply``.
+    """
+
+    def __init__(self, in_features: int, out_features: int, num_kernels: int, basis_func: Any,
+                 num_regions: int, lower_bounds: Sequence[Sequence[float]],
+                 upper_bounds: Sequence[Sequence[float]], dimension_ranges: Sequence[Sequence[int]],
+                 activation_idx: Sequence[int], delta: Sequence[float], centers=None,
+                 fixed_centers: bool = False, fixed_width: bool = False, **_unused):
+        self.in_features = int(in_features)
+        self.out_features = int(out_features)
+        self.num_kernels = int(num_kernels)
+        self.basis_func = basis_name(basis_func)
+        self.num_regions = int(num_regions)
+        self.lower_bounds = [list(map(float, r)) for r in lower_bounds]
+        self.upper_bounds = [list(map(float, r)) for r in upper_bounds]
+        self.dimension_ranges = [list(map(int, r)) for r in dimension_ranges]
+        self.activation_idx = list(activation_idx)
+        self.delta = list(map(float, delta))
+        self.fixed_centers, self.fixed_width = bool(fixed_centers), bool(fixed_width)
+        self.num_split_dimensions = len(self.activation_idx)          # model.py:128
+        ns = self.num_split_dimensions
+        if ns > self.in_features:
+            raise ValueError("len(activation_idx) exceeds in_features")
+        if len(self.lower_bounds) < ns or len(self.upper_bounds) < ns or len(self.delta) < ns:
+            raise ValueError("lower_bounds / upper_bounds / delta must cover every split dimension")
+        for i, r in enumerate(self.dimension_ranges):
+            if len(r) < ns:
+                raise ValueError(f"dimension_ranges[{i}] shorter than the number of split dimensions")
+            for d in range(ns):
+                if not (0 <= r[d] < len(self.lower_bounds[d]) and r[d] < len(self.upper_bounds[d])):
+                    raise IndexError(f"dimension_ranges[{i}][{d}]={r[d]} indexes outside the bounds of dim {d}")
+        self._handles: Dict[int, C.c_void_p] = {}
+        self._bound_fp: Dict[int, tuple] = {}
+        self._keepalive: Dict[int, tuple] = {}
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_config(cls, cfg) -> "WCRBFNet":
+        """cfg: dict, argparse.Namespace or path of a YAML model card (the file the reference writes at
+        scripts/train_nmpc.py:431-450 and reloads at src/irbfn_mpc/irbfn_planner.py:46-79)."""
+        if isinstance(cfg, str):
+            import yaml
+            with open(cfg, "r") as f:
+                cfg = yaml.safe_load(f)
+        elif not isinstance(cfg, dict):
+            cfg = vars(cfg)
+        return cls(**{k: cfg[k] for k in _CFG_FIELDS})
+
+    def config(self) -> dict:
+        return {k: getattr(self, k) for k in _CFG_FIELDS}
+
+    def init(self, seed: int = 0, dtype=np.float32) -> dict:
+        """Fresh parameter pytree with the reference initialisers: centers ~ N(0,1), log_sigs = 0
+        (flax_rbf.py:246-256), Dense kernel lecun_normal, bias 0 (flax.linen.Dense defaults)."""
+        rng = np.random.default_rng(seed)
+        R, K, D, O = self.num_regions, self.num_kernels, self.in_features, self.out_features
+        std = 1.0 / np.sqrt(K) / 0.87962566103423978   # truncated-normal correction of lecun_normal
+        kern = np.clip(rng.normal(size=(K, O)), -2, 2) * std
+        return {"params": {
+            "rbf_list": {"centers": rng.normal(size=(R, K, D)).astype(dtype),
+                         "log_sigs": np.zeros((R, K), dtype)},
+            "linear": {"kernel": kern.astype(dtype), "bias": np.zeros((O,), dtype)}}}
+
+    # ------------------------------------------------------------------ descriptor management
+    def _gate_tables(self):
+        ns = self.num_split_dimensions
+        mr = max([1] + [max(len(self.lower_bounds[d]), len(self.upper_bounds[d])) for d in range(ns)])
+        lo = np.zeros((max(ns, 1), mr), np.float32)
+        hi = np.zeros((max(ns, 1), mr), np.float32)
+        for d in range(ns):
+            lo[d, :len(self.lower_bounds[d])] = self.lower_bounds[d]
+            hi[d, :len(self.upper_bounds[d])] = self.upper_bounds[d]
+        delta = np.asarray(self.delta[:ns] if ns else [0.0], np.float32)
+        nr = min(len(self.dimension_ranges), self.num_regions)   # .at[:, i].set past R is dropped
+        dr = np.asarray([r[:ns] for r in self.dimension_ranges[:nr]], np.int32).reshape(nr, ns)
+        return ns, mr, lo, hi, delta, np.ascontiguousarray(dr), nr
+
+    def _handle(self, torch) -> C.c_void_p:
+        dev = torch.cuda.current_device()
+        h = self._handles.get(dev)
+        if h is None:
+            lib = _lib.load()
+            ns, mr, lo, hi, delta, dr, nr = self._gate_tables()
+            h = C.c_void_p()
+            st = lib.irbfn_net_create(
+                C.byref(h), self.in_features, self.num_regions, self.num_kernels, self.out_features,
+                _lib.BASIS_ENUM[self.basis_func], ns, mr, lo.ctypes.data_as(C.c_void_p),
+                hi.ctypes.data_as(C.c_void_p), delta.ctypes.data_as(C.c_void_p),
+                dr.ctypes.data_as(C.c_void_p), nr)
+            _lib.check(st, "irbfn_net_create")
+            self._handles[dev] = h
+        return h
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for h in self._handles.values():
+                lib.irbfn_net_destroy(h)
+        except Exception:
+            pass
+        self._handles = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _check_shapes(self, p: dict):
+        R, K, D, O = self.num_regions, self.num_kernels, self.in_features, self.out_features
+        want = {"centers": (R, K, D), "log_sigs": (R, K), "kernel": (K, O), "bias": (O,)}
+        got = {"centers": tuple(p["rbf_list"]["centers"].shape), "log_sigs": tuple(p["rbf_list"]["log_sigs"].shape),
+               "kernel": tuple(p["linear"]["kernel"].shape), "bias": tuple(p["linear"]["bias"].shape)}
+        for k in want:
+            if want[k] != got[k]:
+                raise ValueError(f"params {k} has shape {got[k]}, the model card implies {want[k]}")
+
+    @staticmethod
+    def _fingerprint(leaves, torch) -> tuple:
+        fp = []
+        for a in leaves:
+            if isinstance(a, torch.Tensor):
+                fp.append((id(a), a.data_ptr(), a._version))
+            else:
+                return ()           # numpy can be mutated in place unseen: always re-upload
+        return tuple(fp)
+
+    def bind(self, params: dict) -> "WCRBFNet":
+        """Uploads / re-packs the parameter pytree for the current device (irbfn_net_set_params)."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        self._check_shapes(p)
+        leaves = [p["rbf_list"]["centers"], p["rbf_list"]["log_sigs"], p["linear"]["kernel"], p["linear"]["bias"]]
+        dev = torch.cuda.current_device()
+        fp = self._fingerprint(leaves, torch)
+        if fp and self._bound_fp.get(dev) == fp:
+            return self
+        h = self._handle(torch)
+        t = [to_device_f32(a, torch) for a in leaves]
+        st = lib.irbfn_net_set_params(h, _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]), _stream_ptr(torch))
+        _lib.check(st, "irbfn_net_set_params")
+        self._keepalive[dev] = tuple(t)     # until the pack kernel has run
+        self._bound_fp[dev] = fp
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, x):
+        """Forward with the currently bound parameters: x[B,D] -> out[B,O]  (model.py:169-198)."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        if torch.cuda.current_device() not in self._bound_fp:
+            raise ValueError("WCRBFNet: no parameters bound on this device; call apply(params, x) or bind(params)")
+        shape = tuple(x.shape)
+        if len(shape) != 2 or shape[1] != self.in_features:
+            raise ValueError(f"x must have shape (B, {self.in_features}), got {shape}")
+        xd = to_device_f32(x, torch)
+        B = shape[0]
+        out = torch.empty((B, self.out_features), dtype=torch.float32, device=xd.device)
+        if B:
+            st = lib.irbfn_net_forward(self._handle(torch), _ptr(xd), _ptr(out), B, _stream_ptr(torch))
+            _lib.check(st, "irbfn_net_forward")
+        return like_input(out, x, torch)
+
+    def apply(self, params: dict, x):
+        """Drop-in for ``WCRBFNet.apply(params, x)`` / ``state.apply_fn(state.params, x)``
+        (src/irbfn_mpc/irbfn_planner.py:31)."""
+        self.bind(params)
+        return self(x)
+
+    def gate(self, x):
+        """``_region_activation`` (model.py:42-95): x[B,D] -> gamma[B,R]."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        xd = to_device_f32(x, torch)
+        B = xd.shape[0]
+        g = torch.empty((B, self.num_regions), dtype=torch.float32, device=xd.device)
+        if B:
+            _lib.check(lib.irbfn_net_gate(self._handle(torch), _ptr(xd), _ptr(g), B, _stream_ptr(torch)),
+                       "irbfn_net_gate")
+        return like_input(g, x, torch)
+
+    # ------------------------------------------------------------------ backward
+    def vjp(self, params: dict, x, gout) -> dict:
+        """Parameter VJP: cotangent gout[B,O] -> gradient pytree (same structure as ``params``).
+        Replaces ``jax.value_and_grad(loss_fn)(params)`` restricted to the network
+        (scripts/train_nmpc.py:297-298).  Gradients w.r.t. x are never taken by the reference."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        self.bind(params)
+        xd, gd = to_device_f32(x, torch), to_device_f32(gout, torch)
+        B = xd.shape[0]
+        if tuple(gd.shape) != (B, self.out_features):
+            raise ValueError(f"gout must have shape ({B}, {self.out_features}), got {tuple(gd.shape)}")
+        R, K, D, O = self.num_regions, self.num_kernels, self.in_features, self.out_features
+        dev = xd.device
+        gc = torch.empty((R, K, D), dtype=torch.float32, device=dev)
+        gl = torch.empty((R, K), dtype=torch.float32, device=dev)
+        gk = torch.empty((K, O), dtype=torch.float32, device=dev)
+        gb = torch.empty((O,), dtype=torch.float32, device=dev)
+        h = self._handle(torch)
+        nbytes = int(lib.irbfn_net_vjp_workspace_bytes(h, B))
+        ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+        st = lib.irbfn_net_vjp(h, _ptr(xd), _ptr(gd), _ptr(gc), _ptr(gl), _ptr(gk), _ptr(gb), B, _ptr(ws), nbytes,
+                               _stream_ptr(torch))
+        _lib.check(st, "irbfn_net_vjp")
+        conv = (lambda t: like_input(t, x, torch))
+        return {"params": {"rbf_list": {"centers": conv(gc), "log_sigs": conv(gl)},
+                           "linear": {"kernel": conv(gk), "bias": conv(gb)}}}
+
+    def last_launch(self) -> dict:
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        g, b = C.c_int(0), C.c_int(0)
+        lib.irbfn_net_last_launch(self._handle(torch), buf, 128, C.byref(g), C.byref(b))
+        return {"kernel": buf.value.decode(), "grid": g.value, "block": b.value}
+
+
+class _State:
+    """Minimal stand-in of flax's TrainState for ``pred_step``: ``apply_fn`` + ``params``."""
+
+    def __init__(self, apply_fn, params):
+        self.apply_fn, self.params = apply_fn, params
+
+
+def make_state(net: WCRBFNet, params: dict) -> _State:
+    return _State(net.apply, params)
+
+
+def pred_step(state, x):
+    """``pred_step(state, x)`` of src/irbfn_mpc/irbfn_planner.py:29-32."""
+    return state.apply_fn(state.params, x)

@@ -1,0 +1,231 @@
+"""CPU tests of the oracle (test infrastructure): KATs from the reference, NumPy-vs-C cross-check,
+committed golden fixtures, analytic invariants and the hand-derived VJPs against
+torch.autograd (the stand-in for jax.grad).  No GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CKPT_RUNS, GOLDEN, load_ckpt_fixture
+from irbfn_amd import configs
+from oracle import c_oracle as co
+from oracle import hand_vjp as hv
+from oracle import irbfn_oracle as orc
+
+
+# ---------------------------------------------------------------- KATs held by the reference
+def test_kat1_notebook_rollout_float32(kat):
+    """scripts/test_dynamics.ipynb cell 4.  The notebook ran on a CUDA GPU; 34 of the 35 recorded
+    values are reproduced bit-for-bit by the float32 restatement, Y at step 3 differs by 1 ulp
+    (GPU sinf), hence rtol 2.5e-7 rather than equality."""
+    k = kat["kat1"]
+    p = np.array(k["dyn_params"], np.float32)
+    xu = np.hstack([np.zeros((10, 7), np.float32), np.full((10, 10), k["u"], np.float32)])
+    exp = np.array(k["all_states_row"], np.float32)
+    got = orc.integrate_st_mult(xu, p)
+    assert got.dtype == np.float32 and got.shape == (10, 5, 7)
+    assert (got == got[0]).all()
+    np.testing.assert_allclose(got[0], exp, rtol=2.5e-7, atol=0)
+    assert (got[0] == exp).sum() >= 34
+    gc = co.integrate_st_mult(xu, p, 5, np.float32)
+    np.testing.assert_allclose(gc[0], exp, rtol=2.5e-7, atol=0)
+
+
+def _vehicle_params(v):
+    return np.array([v["mu"], v["m"], v["I"], v["lf"], v["lr"], v["C_Sf"], v["C_Sr"], v["h"], 0.1, 0.4, 11.5,
+                     1.066, 50.8])
+
+
+def test_kat2_commonroad_dynamic_rhs(kat):
+    """deprecated/f1tenth_gym/tests/test_dynamics.py:62-70 (f_st_gt): dynamic branch of dynamics.py:49-76."""
+    k = kat["kat2"]
+    p = _vehicle_params(k["vehicle"])
+    f, _, _ = orc.st_rhs(np.array([k["x_st"]]), np.array([k["u"][1]]), np.array([k["u"][0]]), p)
+    assert np.abs(f[0] - np.array(k["f_st_gt"])).max() < 1e-12
+
+
+def test_kat3_commonroad_kinematic_rhs(kat):
+    """test_dynamics.py:55-61 (f_ks_gt): kinematic branch of dynamics.py:78-88."""
+    k, v = kat["kat3"], kat["kat2"]["vehicle"]
+    p = _vehicle_params(v)
+    x = np.array([k["x_ks"] + [0.0, 0.0]])
+    _, fks, _ = orc.st_rhs(x, np.array([k["u"][1]]), np.array([k["u"][0]]), p)
+    assert np.abs(fks[0, :5] - np.array(k["f_ks_gt"])).max() < 1e-12
+
+
+# ---------------------------------------------------------------- golden fixtures + C cross-check
+@pytest.mark.parametrize("run", CKPT_RUNS)
+def test_ckpt_fixture_matches_oracle(run):
+    cfg, params, x, out64, h64, gamma64 = load_ckpt_fixture(run)
+    p64 = orc.cast_params(params, np.float64)
+    out, h, gam = orc.wcrbfnet_apply(cfg, p64, x, return_aux=True)
+    np.testing.assert_allclose(out, out64, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gam, gamma64, rtol=1e-12, atol=1e-14)
+    outc = co.wcrbf_forward(cfg, p64, x, np.float64)
+    np.testing.assert_allclose(outc, out64, rtol=1e-9, atol=1e-9 * np.abs(out64).max())
+    # the float32 path (what the reference runs by default) stays close to float64 relative to the
+    # magnitude of the summed terms (trained kernels reach +-800, SURVEY section 7 "hard parts")
+    out32 = co.wcrbf_forward(cfg, p64, x, np.float32)
+    scale = (np.abs(h64) @ np.abs(np.asarray(params["params"]["linear"]["kernel"], np.float64))).max()
+    assert np.abs(out32 - out64).max() <= 2e-5 * scale
+
+
+def test_synth_cfg1_fixture():
+    cfg = configs.model_card(1)
+    x = configs.synth_queries(1, dtype=np.float64)
+    out = orc.wcrbfnet_apply(cfg, configs.synth_params(1, np.float64), x)
+    exp = np.load(os.path.join(GOLDEN, "synth_cfg1.npz"))["out64"]
+    np.testing.assert_allclose(out, exp, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", sorted(orc.BASIS))
+def test_c_oracle_all_bases(name):
+    cfg = dict(configs.model_card(1), basis_func=name)
+    P = configs.synth_params(1, np.float64)
+    x = configs.synth_queries(1, B=64, dtype=np.float64)
+    a = orc.wcrbfnet_apply(cfg, P, x)
+    b = co.wcrbf_forward(cfg, P, x, np.float64)
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(a).max()))
+
+
+def test_c_oracle_rollouts_match_numpy():
+    rng = np.random.default_rng(0)
+    dp = np.array(orc.DYN_PARAMS_KAT1)
+    for T in (1, 5, 12):
+        xu = np.hstack([rng.normal(size=(50, 7)) * [1, 1, .3, 4, 1, .5, .1], rng.normal(size=(50, 2 * T)) * 3])
+        np.testing.assert_allclose(orc.integrate_st_mult(xu, dp), co.integrate_st_mult(xu, dp, T, np.float64),
+                                   rtol=0, atol=1e-13)
+        np.testing.assert_allclose(orc.integrate_st_ks_mult(xu, dp),
+                                   co.integrate_st_mult(xu, dp, T, np.float64, True), rtol=0, atol=1e-13)
+        xf = np.hstack([rng.normal(size=(50, 8)) * .3 + [0, 0, 0, 4, 0, 0, 0, 0], rng.normal(size=(50, 2 * T)) * 3])
+        np.testing.assert_allclose(orc.integrate_frenet_mult(xf, dp), co.integrate_frenet_mult(xf, dp, T, np.float64),
+                                   rtol=0, atol=1e-13)
+        v0, u = rng.uniform(0, 7, 50), rng.normal(size=(50, 2 * T)) * 3
+        np.testing.assert_allclose(orc.rollout_fullint(v0, u), co.rollout_fullint(v0, u, T, np.float64), atol=1e-13)
+    q = np.hstack([rng.normal(size=(50, 4)) * .3, rng.uniform(1, 10, size=(50, 1))])
+    np.testing.assert_allclose(orc.integrate_path_mult(q), co.integrate_path_mult(q, 9, np.float64), atol=1e-12)
+
+
+# ---------------------------------------------------------------- invariants
+def test_invariant_query_on_centre_phi_one():
+    c = np.random.default_rng(1).normal(size=(1, 5, 3))
+    ls = np.zeros((1, 5))
+    for b in ("gaussian", "inverse_quadratic", "inverse_multiquadric"):
+        phi = orc.rbf_layer(c[0], c, ls, b)
+        np.testing.assert_allclose(np.diagonal(phi[:, 0, :]), 1.0, atol=1e-15)
+
+
+def test_invariant_far_bounds_gate_is_one():
+    cfg = dict(configs.model_card(1), lower_bounds=[[-1e6]] * 3, upper_bounds=[[1e6]] * 3)
+    x = configs.synth_queries(1, B=32, dtype=np.float64)
+    P = configs.synth_params(1, np.float64)
+    out, h, gam = orc.wcrbfnet_apply(cfg, P, x, return_aux=True)
+    np.testing.assert_allclose(gam, 1.0, atol=1e-15)
+    p = P["params"]
+    phi = orc.rbf_layer(x, p["rbf_list"]["centers"], p["rbf_list"]["log_sigs"], "gaussian")[:, 0]
+    np.testing.assert_allclose(out, phi @ p["linear"]["kernel"] + p["linear"]["bias"], rtol=1e-13)   # == RBFNet
+
+
+def test_invariant_regions_without_range_are_zero():
+    cfg = dict(configs.model_card(1), num_regions=3)      # R = 3 but only one dimension_range (App. B-2)
+    x = configs.synth_queries(1, B=8, dtype=np.float64)
+    gam = orc.region_activation(x, 3, 3, cfg["lower_bounds"], cfg["upper_bounds"], cfg["delta"], cfg["dimension_ranges"])
+    assert (gam[:, 1:] == 0).all() and (gam[:, 0] > 0).any()
+
+
+def test_invariant_spiral_zero_curvature_is_straight_line():
+    q = np.array([[0.0, 0.0, 0.0, 0.0, 7.5]])
+    st = orc.integrate_path_mult(q)
+    np.testing.assert_allclose(st[0, -1, :3], [7.5, 0.0, 0.0], atol=1e-14)
+    np.testing.assert_allclose(st[0, :, 0], np.linspace(0, 7.5, 9), atol=1e-14)
+
+
+def test_invariant_rollout_mirror_symmetry():
+    rng = np.random.default_rng(3)
+    dp = np.array(orc.DYN_PARAMS_KAT1)
+    T = 5
+    xu = np.hstack([rng.normal(size=(20, 7)) * [1, 1, .2, 2, .5, 0, 0], rng.normal(size=(20, 2 * T))])
+    xu[:, 3] = np.abs(xu[:, 3])
+    m = xu.copy()
+    m[:, [1, 2, 4]] *= -1          # y, delta, psi
+    m[:, 7 + T:] *= -1             # steering velocity
+    a, b = orc.integrate_st_ks_mult(xu, dp), orc.integrate_st_ks_mult(m, dp)
+    sign = np.array([1, -1, -1, 1, -1, 1, 1.0])
+    np.testing.assert_allclose(a, b * sign, atol=1e-13)
+
+
+def test_spiral_s_zero_propagates_nan():
+    with np.errstate(all="ignore"):
+        st = orc.integrate_path_mult(np.array([[0.1, 0.2, 0.1, 0.0, 0.0]]))
+    assert np.isnan(st).any()      # planner_utils.py:26-28 divides by s (App. B-8)
+
+
+# ---------------------------------------------------------------- hand VJPs vs autograd
+def test_hand_net_vjp_matches_autograd():
+    for run in ("dnmpc_128regions", "dnmpc_12regions_frenet_l1_bigdata"):
+        cfg, params, x, *_ = load_ckpt_fixture(run)
+        x = x[:16]
+        g = np.random.default_rng(5).normal(size=(16, cfg["out_features"]))
+        tp = orc.torch_params(params, torch.float64, requires_grad=True)
+        out = orc.wcrbfnet_apply(cfg, tp, torch.tensor(x))
+        (out * torch.tensor(g)).sum().backward()
+        hand = orc.wcrbfnet_vjp(cfg, params, x, g)["params"]
+        p = tp["params"]
+        for (a, b) in ((hand["rbf_list"]["centers"], p["rbf_list"]["centers"].grad),
+                       (hand["rbf_list"]["log_sigs"], p["rbf_list"]["log_sigs"].grad),
+                       (hand["linear"]["kernel"], p["linear"]["kernel"].grad),
+                       (hand["linear"]["bias"], p["linear"]["bias"].grad)):
+            np.testing.assert_allclose(a, b.numpy(), rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b.numpy()).max()))
+
+
+def _ag(fn, *arrs):
+    ts = [torch.tensor(a, requires_grad=True) for a in arrs]
+    return ts, fn(*ts)
+
+
+def test_hand_rollout_vjps_match_autograd():
+    rng = np.random.default_rng(11)
+    dp = np.array(orc.DYN_PARAMS_KAT1)
+    B, T = 48, 6
+    # kinematic single track
+    xu = np.hstack([rng.normal(size=(B, 7)) * [1, 1, .4, 5, 1, .5, .1], rng.normal(size=(B, 2 * T)) * 6.0])
+    xu[:, 7 + T:] *= 0.5
+    gs = rng.normal(size=(B, T, 7))
+    (t,), st = _ag(lambda a: orc.integrate_st_ks_mult(a, dp), xu)
+    (st * torch.tensor(gs)).sum().backward()
+    np.testing.assert_allclose(hv.vjp_st_ks(xu, dp, gs), t.grad.numpy(), atol=1e-12)
+    # inline bicycle
+    v0, u = rng.uniform(-1, 8, B), rng.normal(size=(B, 2 * T)) * 5
+    g5 = rng.normal(size=(B, T, 5))
+    (tv, tu), st = _ag(orc.rollout_fullint, v0, u)
+    (st * torch.tensor(g5)).sum().backward()
+    gv, gu = hv.vjp_fullint(v0, u, g5)
+    np.testing.assert_allclose(gv, tv.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(gu, tu.grad.numpy(), atol=1e-12)
+    # Frenet
+    xf = np.hstack([rng.normal(size=(B, 8)) * .3 + [0, 0, 0, 4, 0, 0, 0, 0], rng.normal(size=(B, 2 * T)) * 4])
+    g8 = rng.normal(size=(B, T, 8))
+    (t,), st = _ag(lambda a: orc.integrate_frenet_mult(a, dp), xf)
+    (st * torch.tensor(g8)).sum().backward()
+    np.testing.assert_allclose(hv.vjp_frenet(xf, dp, g8), t.grad.numpy(), atol=1e-11)
+    # spiral
+    q = np.hstack([rng.normal(size=(B, 4)) * .3, rng.uniform(1, 10, size=(B, 1))])
+    g6 = rng.normal(size=(B, 9, 6))
+    (t,), st = _ag(orc.integrate_path_mult, q)
+    (st * torch.tensor(g6)).sum().backward()
+    ref = t.grad.numpy()
+    np.testing.assert_allclose(hv.vjp_spiral(q, g6), ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+
+
+def test_oneint_loss_value_and_grad_finite():
+    """Loss composition of train_step_oneint (scripts/train_nmpc.py:268-295) on a fixture batch."""
+    cfg, params, x, *_ = load_ckpt_fixture("dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq")
+    y = np.random.default_rng(2).normal(size=(64, 2))
+    dp = np.array(orc.DYN_PARAMS_KAT1)
+    tp = orc.torch_params(params, torch.float64, requires_grad=True)
+    loss = orc.train_oneint_loss(cfg, tp, torch.tensor(x), torch.tensor(y), dp)
+    loss.backward()
+    lv = orc.train_oneint_loss(cfg, orc.cast_params(params, np.float64), x, y, dp)
+    assert abs(float(loss) - float(lv)) < 1e-12 * max(1.0, abs(float(lv)))
+    assert all(torch.isfinite(l.grad).all() for l in (tp["params"]["rbf_list"]["centers"], tp["params"]["linear"]["kernel"]))
