@@ -18,15 +18,21 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libirbfn_hip.so")
 ARCH = "gfx950"
 
+_SLP = ["-fno-slp-vectorize"] if os.environ.get("IRBFN_NO_SLP") == "1" else []
+
 # (source, object name, extra flags)
 UNITS = [
     ("abi.hip", "abi.o", []),
     ("rbf_forward.hip", "rbf_forward.o", []),
-    ("rbf_forward_kernels.hip", "rbf_fwd_d3.o", ["-DIRBFN_INST_D=3"]),
-    ("rbf_forward_kernels.hip", "rbf_fwd_d4.o", ["-DIRBFN_INST_D=4"]),
-    ("rbf_forward_kernels.hip", "rbf_fwd_d7.o", ["-DIRBFN_INST_D=7"]),
-    ("rbf_forward_kernels.hip", "rbf_fwd_d8.o", ["-DIRBFN_INST_D=8"]),
-    ("rbf_vjp.hip", "rbf_vjp.o", []),
+    # NOTE on -fno-slp-vectorize (IRBFN_NO_SLP=1): hipcc's SLP vectoriser fuses the weight-row FMAs
+    # into v_pk_fma_f32 with an SGPR-pair operand; measured on MI355X (cfg-2) the packed form is
+    # FASTER than ten v_fmac_f32 with SGPR operands (152 vs 173 us), so SLP stays on by default.
+    ("rbf_forward_kernels.hip", "rbf_fwd_d3.o", ["-DIRBFN_INST_D=3"] + _SLP),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d4.o", ["-DIRBFN_INST_D=4"] + _SLP),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d7.o", ["-DIRBFN_INST_D=7"] + _SLP),
+    ("rbf_forward_kernels.hip", "rbf_fwd_d8.o", ["-DIRBFN_INST_D=8"] + _SLP),
+    ("rbf_forward_mfma.hip", "rbf_fwd_mfma.o", []),
+    ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rollout.hip", "rollout.o", []),
     ("rollout_vjp.hip", "rollout_vjp.o", []),
 ]

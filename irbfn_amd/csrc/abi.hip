@@ -77,6 +77,8 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   alloc((void**)&net->rec, (size_t)net->N * net->S * sizeof(float));
   alloc((void**)&net->bias, (size_t)OP * sizeof(float));
   alloc((void**)&net->sig2, (size_t)net->N * sizeof(float));
+  net->Npad = (net->N + 15) & ~15;
+  if (mfma_eligible(net)) alloc((void**)&net->recm, (size_t)net->Npad * mfma_record_floats(D, O) * sizeof(float));
   alloc((void**)&net->gate_lo, tab * sizeof(float));
   alloc((void**)&net->gate_hi, tab * sizeof(float));
   alloc((void**)&net->gate_delta, (size_t)(nsplit > 0 ? nsplit : 1) * sizeof(float));
@@ -101,7 +103,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
 
 int irbfn_net_destroy(irbfn_net* net) {
   if (!net) return IRBFN_OK;
-  void* bufs[] = {net->rec, net->bias, net->sig2, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete net;
@@ -112,6 +114,7 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
                          const float* kernel_dev, const float* bias_dev, void* stream) {
   if (!net || !centers_dev || !log_sigs_dev || !kernel_dev || !bias_dev) return IRBFN_ERR_BAD_ARG;
   int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
+  if (rc == IRBFN_OK && net->recm) rc = launch_pack_mfma(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
 }

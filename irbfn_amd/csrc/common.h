@@ -66,6 +66,8 @@ struct irbfn_net {
   float* rec;   // [N][S]   packed records (device)
   float* bias;  // [OP]     (device, zero padded)
   float* sig2;  // [N]      exp(-2 log_sig) (device) -- VJP
+  float* recm;  // [Npad][CW + 16*NT] records of the MFMA forward (K1m); NULL if not eligible
+  int Npad;     // N rounded up to a multiple of 16 (MFMA chunk)
   // raw parameter pointers are NOT kept: set_params copies what it needs
   float* gate_lo;
   float* gate_hi;
@@ -86,6 +88,11 @@ namespace irbfn {
 int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
                 const float* bias, hipStream_t s);
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
+bool mfma_eligible(const irbfn_net* net);
+size_t mfma_record_floats(int D, int O);
+int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
+                     hipStream_t s);
+int launch_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, int QJ, int nw, hipStream_t s);
 int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStream_t s);
 int64_t vjp_workspace_bytes(const irbfn_net* net, int64_t B);
 int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_centers, float* g_log_sigs,

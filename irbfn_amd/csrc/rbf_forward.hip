@@ -121,17 +121,19 @@ static int pow2_floor(int v) {
 static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   const int OP = net->OP;
   const bool gated = net->R > 1;
-  // --- Q: two queries per lane halve the scalar-stream traffic per pair; only with enough tiles
+  // --- Q: two queries per lane halve the scalar-stream traffic per pair, but the kernel is VALU-issue
+  // bound and more resident waves hide the scalar-load latency better (measured: Q=1,NW=16 152 us vs
+  // Q=2,NW=16 175 us at cfg-2), so Q = 2 only once Q = 1 alone over-subscribes the chip.
   int Q = 1;
   const bool q2_compiled = (OP == 2 || OP == 5 || OP == 10);
-  if (q2_compiled && a.B >= 2 * kWave * 512) Q = 2;
+  if (q2_compiled && a.B >= (long)kWave * 32768) Q = 2;
   Q = env_int("IRBFN_FWD_Q", Q);
   if (Q != 1 && !(Q == 2 && q2_compiled)) Q = 1;
   const int ROWS = kWave * Q;
   const long tiles = (a.B + ROWS - 1) / ROWS;
   // --- NW: enough waves to cover the chip (1024 SIMDs) several times, >= 32 centres per wave
   const int max_threads = (OP * Q > 48) ? 512 : 1024;
-  long want = (8192 + tiles - 1) / tiles;
+  long want = (16384 + tiles - 1) / tiles;
   int nw = want < 1 ? 1 : (want > 16 ? 16 : (int)want);
   nw = pow2_floor(nw);
   while (nw > 1 && net->N / nw < 32) nw /= 2;
@@ -186,8 +188,29 @@ static void fill_args(irbfn_net* net, FwdArgs& a, const float* x, float* out, in
   a.basis = net->basis;
 }
 
+// K1m (Phi x W on the f32 matrix cores).  Opt-in (IRBFN_FWD_MFMA=1): measured on MI355X at cfg-2 it is
+// SLOWER than K1 (169-217 us vs 152 us): the f32-input MFMA runs at the fp32 vector rate and does not
+// overlap with the VALU distance/basis work, so with O = 10 padded to a 16-wide tile it buys nothing.
+// Kept as the "reduction expressed as a dense GEMM" variant that BASELINE config 5 asks to report.
+static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
+  if (!net->recm || env_int("IRBFN_FWD_MFMA", 0) == 0) return IRBFN_ERR_UNSUPPORTED;
+  int QJ = env_int("IRBFN_FWD_QJ", 4);
+  if (QJ != 1 && QJ != 2 && QJ != 4) QJ = 4;
+  const long tiles = (B + 16 * QJ - 1) / (16 * QJ);
+  long want = (8192 + tiles - 1) / tiles;
+  int nw = want < 1 ? 1 : (want > 16 ? 16 : (int)want);
+  nw = pow2_floor(nw);
+  const int chunks = net->Npad / 16;
+  while (nw > 1 && chunks / nw < 2) nw /= 2;
+  nw = env_int("IRBFN_FWD_NW", nw);
+  if (nw < 1) nw = 1;
+  if (nw > 16) nw = 16;
+  return launch_forward_mfma(net, x, out, B, QJ, nw, s);
+}
+
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (B == 0) return IRBFN_OK;
+  if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
   FwdArgs a;
   fill_args(net, a, x, out, B);
   return run_forward(net, a, false, s);

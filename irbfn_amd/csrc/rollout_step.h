@@ -15,6 +15,7 @@ __device__ __forceinline__ float clipf(float v, float lo, float hi) {
 // SELECT=false: kinematic RHS only = dynamic_st_onestep_aux (:103-187).
 template <bool SELECT>
 __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_in, const DynParams& dp) {
+#pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float g = 9.81f;                                 // dynamics.py:6
   const float mu = dp.p[0], m = dp.p[1], I = dp.p[2], lf = dp.p[3], lr = dp.p[4], C_Sf = dp.p[5],
               C_Sr = dp.p[6], h = dp.p[7], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10],
@@ -55,6 +56,7 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
 
 // Inline kinematic bicycle of train_step_fullint, scripts/train_nmpc.py:329-347 / :356-374.
 __device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv) {
+#pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float DT = 0.1f, WB = 0.33f, VMAX = 7.0f, VMIN = 0.0f, SMAX = 0.4189f;   // :307-311
   s[0] = s[0] + s[3] * cosf(s[4]) * DT;                  // :360
   s[1] = s[1] + s[3] * sinf(s[4]) * DT;                  // :361
@@ -65,6 +67,7 @@ __device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv) {
 
 // Frenet model, low-speed RHS only, src/irbfn_mpc/dynamics.py:190-281 (:267-280).
 __device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_in, const DynParams& dp) {
+#pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float LF = dp.p[3], LR = dp.p[4], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10],
               s_max = dp.p[11];
   const float ey = s[1], delta = clipf(s[2], -s_max, s_max), vx = s[3], epsi = s[6], cur = s[7];
@@ -86,6 +89,7 @@ __device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_
 
 // Cubic spiral: params_to_coefs (planner_utils.py:20-29)
 __device__ __forceinline__ void spiral_coefs(const float (&q)[5], float (&c)[4]) {
+#pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float s = q[4];
   c[0] = 1.0f * q[0] + 0.0f * q[1] + 0.0f * q[2] + 0.0f * q[3];           // PARAM_MAT :10-17
   c[1] = (-11.0f / 2) * q[0] + 9.0f * q[1] + (-9.0f / 2) * q[2] + 1.0f * q[3];
@@ -98,6 +102,7 @@ __device__ __forceinline__ void spiral_coefs(const float (&q)[5], float (&c)[4])
 
 // integrate_one_step (planner_utils.py:44-59); st = [x, y, theta, kappa, dx, dy]; i = 0-based sample
 __device__ __forceinline__ void spiral_step(float (&st)[6], const float (&c)[4], float s, int i, int N) {
+#pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float sk = (i < N - 1) ? s * ((float)i / (float)(N - 1)) : s;      // jnp.linspace(0, s, N) :71
   const float k = (float)(i + 1);                                          // :72
   float kap = 0.0f, th = 0.0f, pw = 1.0f;
