@@ -1,12 +1,12 @@
 // K3: stand-alone roll-out kernels (forward).  One lane integrates one trajectory, the state lives
-// in VGPRs for all T steps.  The kernels are HBM-bound (1.8 KB of traffic per trajectory at T = 50
-// against ~10 kFLOP): a wave's 64 input rows form ONE contiguous chunk of HBM, so it is copied into
-// LDS with coalesced 16-byte loads and read back row-wise; the states are staged per time-chunk in
-// LDS and flushed as contiguous row segments.
+// in VGPRs for all T steps.  Traffic is 1.8 KB per trajectory at T = 50 against ~10 kFLOP, so HBM is
+// the roof -- but only if enough waves are resident to hide the long dependent trig chains of a step.
 //
 // Replaces integrate_st_mult (src/irbfn_mpc/dynamics.py:94-100), dynamic_st_onestep_aux (:103-187),
 // integrate_frenet_mult (:284-290), the inline bicycle of scripts/train_nmpc.py:329-374 and
 // integrate_path_mult (src/irbfn_mpc/planner_utils.py:62-77).
+#include <stdlib.h>
+
 #include "common.h"
 #include "rollout_step.h"
 
@@ -51,46 +51,53 @@ struct RollArgs {
   const float* __restrict__ x0u;   // [B][L]
   float* __restrict__ states;      // [B][T][S]
   long B;
-  int T, L, TS;                    // TS = steps staged per LDS flush
-  int stage_in;                    // 1: input tile staged in LDS
+  int T, L;
+  int dbg;                         // diagnosis only (IRBFN_ROLL_DBG): 1 = skip stores, 2 = skip control loads
   DynParams dp;
 };
 
-// LDS: [in tile: 64*L floats (if stage_in)] [out tile: 64 * (TS*S + 1) floats]
+// 16-byte vector with 4-byte alignment: the input rows are only dword aligned (L is odd), gfx950
+// handles the unaligned global_load_dwordx4
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kRollWaves = 4;      // waves per workgroup (independent; wave-private LDS)
+constexpr int kRollTS = 4;         // steps staged per flush = controls fetched per 16-byte load
+
+// What makes this kernel fast (each item measured, profiles/r01_rollout_*):
+//  * occupancy: one step is a long DEPENDENT chain, so a SIMD needs several resident waves; LDS is
+//    kept to one 64 x 33-float tile per wave (8.4 KB), shared by the input and output staging;
+//  * straight-line sin/cos/tan (rollout_step.h) instead of ocml's branchy range reduction;
+//  * 16-byte accesses: controls 128 contiguous bytes per stream per lane at a time, states flushed
+//    through the LDS tile as row runs of TS*S floats.
+// Known limit (profiles/r01_rollout_notes.md): the rows are only dword aligned and gfx950 splits
+// unaligned 16-byte accesses, so loads, compute and stores add up instead of overlapping
+// (compute 67 us + loads 72 us + stores 110 us at B = 262144, T = 50); the next step is a
+// sliding-window flush that writes only aligned float4 pieces.
 template <int MODE>
-__global__ __launch_bounds__(64) void rollout_fwd_kernel(const RollArgs a) {
+__global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const RollArgs a) {
   extern __shared__ float lds[];
   constexpr int S = ModeTraits<MODE>::S;
   constexpr int S0 = ModeTraits<MODE>::S0;
-  const int lane = threadIdx.x;
-  const long b0 = (long)blockIdx.x * kWave;
+  constexpr int TS = kRollTS;
+  constexpr int TCH = 32;                        // steps per control chunk (128 bytes per stream per row)
+  constexpr int PITCH = 33;                      // >= max(TS*S, TCH), odd: conflict-free row-wise access
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long b0 = ((long)blockIdx.x * kRollWaves + wave) * kWave;
+  if (b0 >= a.B) return;                         // whole wave out of range (no block-level barriers used)
   const long left = a.B - b0;
   const int nvalid = left < kWave ? (int)left : kWave;
   const int L = a.L, T = a.T;
-
-  const float* row;                              // this lane's input row (LDS or HBM)
-  float* outt;
-  if (a.stage_in) {
-    const float* src = a.x0u + b0 * L;
-    const int total = nvalid * L;
-    // the tile base b0*L*4 bytes is 16-byte aligned (b0 is a multiple of 64)
-    const int n4 = total >> 2;
-    const float4* src4 = reinterpret_cast<const float4*>(src);
-    float4* dst4 = reinterpret_cast<float4*>(lds);
-    for (int i = lane; i < n4; i += kWave) dst4[i] = src4[i];
-    for (int i = (n4 << 2) + lane; i < total; i += kWave) lds[i] = src[i];
-    __syncthreads();                             // one wave per workgroup: cheap
-    const int rr = lane < nvalid ? lane : nvalid - 1;
-    row = lds + rr * L;
-    outt = lds + ((kWave * L + 3) & ~3);
-  } else {
-    const long bb = (b0 + lane) < a.B ? (b0 + lane) : a.B - 1;
-    row = a.x0u + bb * L;
-    outt = lds;
-  }
-  const int TSS = a.TS * S;                      // floats per row per flush
-  const int pitch = TSS | 1;                     // odd pitch: conflict-free row-wise writes
-  float* myout = outt + lane * pitch;
+  const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
+  const float* row = a.x0u + bb * L;
+  static_assert(TS * S <= 32, "output chunk must fit the tile");
+  float* outt = lds + wave * (kWave * PITCH);
+  float* myout = outt + lane * PITCH;
+  auto wave_sync = [&]() {                       // wave-private LDS: in-order queue, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   float* gout = a.states + b0 * (long)T * S;     // tile base in HBM; row stride T*S
 
   float s[S];
@@ -111,49 +118,89 @@ __global__ __launch_bounds__(64) void rollout_fwd_kernel(const RollArgs a) {
     for (int i = 0; i < S; ++i) s[i] = row[i];
   }
 
-  for (int t0 = 0; t0 < T; t0 += a.TS) {
-    const int tn = (T - t0) < a.TS ? (T - t0) : a.TS;
-    for (int tt = 0; tt < tn; ++tt) {
-      const int t = t0 + tt;
-      if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, row[S0 + t], row[S0 + T + t], a.dp);
-      else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, row[S0 + t], row[S0 + T + t], a.dp);
-      else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, row[S0 + t], row[S0 + T + t]);
-      else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, row[S0 + t], row[S0 + T + t], a.dp);
-      else spiral_step(s, coef, slen, t, T);
+  // Controls: each lane streams its own row, 128 contiguous bytes per stream at a time (TCH = 32
+  // steps = 8 x 16-byte loads per stream, all issued back to back -> one wait per chunk).
+  for (int tc = 0; tc < T; tc += TCH) {
+    float ua[TCH], us[TCH];
+    if constexpr (MODE != IRBFN_ROLLOUT_SPIRAL) {
 #pragma unroll
-      for (int i = 0; i < S; ++i) myout[tt * S + i] = s[i];
+      for (int i4 = 0; i4 < TCH / 4; ++i4) {
+        const int t = tc + 4 * i4;
+        if (a.dbg & 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ua[4 * i4 + i] = 0.5f; us[4 * i4 + i] = 0.1f; }
+        } else if (t + 3 < T) {                  // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
+          const f4u va = *reinterpret_cast<const f4u*>(row + S0 + t);
+          const f4u vs = *reinterpret_cast<const f4u*>(row + S0 + T + t);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ua[4 * i4 + i] = va[i]; us[4 * i4 + i] = vs[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            ua[4 * i4 + i] = (t + i) < T ? row[S0 + t + i] : 0.0f;
+            us[4 * i4 + i] = (t + i) < T ? row[S0 + T + t + i] : 0.0f;
+          }
+        }
+      }
     }
-    __syncthreads();
-    // flush: row r, segment [t0*S, t0*S + tn*S) -> contiguous tn*S floats at gout + r*T*S + t0*S
-    const int seg = tn * S;
-    for (int idx = lane; idx < nvalid * seg; idx += kWave) {
-      const int r = idx / seg, c = idx - r * seg;
-      gout[(long)r * T * S + t0 * S + c] = outt[r * pitch + c];
+#pragma unroll
+    for (int ts = 0; ts < TCH; ts += TS) {
+      const int t0 = tc + ts;
+      if (t0 < T) {
+        const int tn = (T - t0) < TS ? (T - t0) : TS;
+#pragma unroll
+        for (int tt = 0; tt < TS; ++tt) {
+          if (tt < tn) {
+            if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[ts + tt], us[ts + tt], a.dp);
+            else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[ts + tt], us[ts + tt], a.dp);
+            else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[ts + tt], us[ts + tt]);
+            else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[ts + tt], us[ts + tt], a.dp);
+            else spiral_step(s, coef, slen, t0 + tt, T);
+#pragma unroll
+            for (int i = 0; i < S; ++i) myout[tt * S + i] = s[i];
+          }
+        }
+        wave_sync();
+        // flush: row r, run [t0*S, t0*S + tn*S) -> contiguous tn*S floats at gout + r*T*S + t0*S, as
+        // 16-byte pieces (TS*S/4 lanes per row, RPI rows per store instruction).
+        constexpr int P4 = (TS * S) / 4;
+        constexpr int RPI = kWave / P4;
+        if (tn == TS) {
+          const int rsub = lane / P4, part = lane - rsub * P4;
+          if (rsub < RPI) {
+#pragma unroll
+            for (int j = 0; j < (kWave + RPI - 1) / RPI; ++j) {
+              const int r = j * RPI + rsub;
+              if (r < nvalid) {
+                const float* src = outt + r * PITCH + 4 * part;
+                f4u v;
+                v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+                if (!(a.dbg & 1) || v[0] == 12345.678f)
+                  *reinterpret_cast<f4u*>(gout + (long)r * T * S + t0 * S + 4 * part) = v;
+              }
+            }
+          }
+        } else {
+          const int seg = tn * S;
+          for (int idx = lane; idx < nvalid * seg; idx += kWave) {
+            const int r = idx / seg, c = idx - r * seg;
+            gout[(long)r * T * S + t0 * S + c] = outt[r * PITCH + c];
+          }
+        }
+        wave_sync();
+      }
     }
-    __syncthreads();
   }
 }
 
 template <int MODE>
-static int launch_mode(const RollArgs& a0, hipStream_t s) {
-  RollArgs a = a0;
+static int launch_mode(const RollArgs& a, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
-  // stage the input tile if it fits a modest LDS budget; chunk the output to <= ~16 KB per wave
-  a.stage_in = ((size_t)kWave * a.L * 4 <= 40 * 1024) ? 1 : 0;
-  int TS = (16 * 1024) / (kWave * S * 4);
-  if (TS < 1) TS = 1;
-  if (TS > a.T) TS = a.T;
-  a.TS = TS;
-  const size_t in_f = a.stage_in ? (((size_t)kWave * a.L + 3) & ~(size_t)3) : 0;
-  const size_t lds = (in_f + (size_t)kWave * ((TS * S) | 1)) * sizeof(float);
-  auto kern = rollout_fwd_kernel<MODE>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }
-  }
-  const long grid = (a.B + kWave - 1) / kWave;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWave), lds, s, a);
+  (void)S;
+  const size_t lds = (size_t)kRollWaves * kWave * 33 * sizeof(float);
+  const long waves = (a.B + kWave - 1) / kWave;
+  const long grid = (waves + kRollWaves - 1) / kRollWaves;
+  hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -167,8 +214,7 @@ int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, floa
   a.B = (long)B;
   a.T = T;
   a.L = rollout_input_dim(mode, T);
-  a.TS = 1;
-  a.stage_in = 0;
+  a.dbg = getenv("IRBFN_ROLL_DBG") ? atoi(getenv("IRBFN_ROLL_DBG")) : 0;
   a.dp = dp;
   switch (mode) {
     case IRBFN_ROLLOUT_ST_SELECT: return launch_mode<IRBFN_ROLLOUT_ST_SELECT>(a, s);

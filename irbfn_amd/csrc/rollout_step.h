@@ -6,6 +6,41 @@
 
 namespace irbfn {
 
+// Straight-line sin/cos for the roll-outs.  ocml's sinf/cosf/tanf cost ~430 VALU instructions per
+// step with divergent range-reduction branches; one step is a serial dependent chain, so the stand-
+// alone roll-out was latency bound at 14-24 % of HBM.  Here: Cody-Waite reduction by pi/2 with three
+// FMA steps (exact to |x| < 8192, beyond that the ocml path), cephes minimax polynomials on
+// [-pi/4, pi/4] (<= 1 ulp each), quadrant select.  Total error <= 2 ulp; one reduction serves sin and cos.
+__device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
+  if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) {   // huge, inf or nan: accurate slow path
+    sn = sinf(x);
+    cs = cosf(x);
+    return;
+  }
+  const float kf = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  float r = __builtin_fmaf(-kf, 1.57079625129699707031e+00f, x);
+  r = __builtin_fmaf(-kf, 7.54978941586159635335e-08f, r);
+  r = __builtin_fmaf(-kf, 5.39030285815811905290e-15f, r);
+  const float r2 = r * r;
+  float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = __builtin_fmaf(sp, r2, -1.6666654611e-1f);
+  sp = __builtin_fmaf(sp * r2, r, r);
+  float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = __builtin_fmaf(cp, r2, 4.166664568298827e-2f);
+  cp = __builtin_fmaf(cp * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  const int k = (int)kf;
+  const float a = (k & 1) ? cp : sp;                  // sin: sp, cp, -sp, -cp
+  const float b = (k & 1) ? sp : cp;                  // cos: cp, -sp, -cp, sp
+  sn = (k & 2) ? -a : a;
+  cs = ((k + 1) & 2) ? -b : b;
+}
+
+__device__ __forceinline__ float tan_fast(float x) {
+  float sn, cs;
+  sincos_fast(x, sn, cs);
+  return sn / cs;
+}
+
 __device__ __forceinline__ float clipf(float v, float lo, float hi) {
   // jnp.clip = min(max(v, lo), hi); NaN propagates (fmaxf alone would swallow it)
   return v != v ? v : fminf(fmaxf(v, lo), hi);
@@ -27,8 +62,10 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
   const float SV = clipf(sv_in, -sv_max, sv_max);        // :47
   float f0, f1, f4, f5, f6;
   if (SELECT && V > 3.0f) {                              // :49-76
-    f0 = V * cosf(PSI + BETA);
-    f1 = V * sinf(PSI + BETA);
+    float sn, cs;
+    sincos_fast(PSI + BETA, sn, cs);
+    f0 = V * cs;
+    f1 = V * sn;
     f4 = PSI_DOT;
     const float glr = g * lr - ACCL * h, glf = g * lf + ACCL * h;
     f5 = ((mu * m) / (I * (lf + lr))) *
@@ -39,9 +76,11 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
               (C_Sr * glf * lr - C_Sf * glr * lf) * (PSI_DOT / V)) -
          PSI_DOT;
   } else {                                               // :78-88
-    f0 = V * cosf(PSI);
-    f1 = V * sinf(PSI);
-    f4 = (V / (lr + lf)) * tanf(DELTA);
+    float sn, cs;
+    sincos_fast(PSI, sn, cs);
+    f0 = V * cs;
+    f1 = V * sn;
+    f4 = (V / (lr + lf)) * tan_fast(DELTA);
     f5 = 0.0f;
     f6 = 0.0f;
   }
@@ -58,11 +97,13 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
 __device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv) {
 #pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float DT = 0.1f, WB = 0.33f, VMAX = 7.0f, VMIN = 0.0f, SMAX = 0.4189f;   // :307-311
-  s[0] = s[0] + s[3] * cosf(s[4]) * DT;                  // :360
-  s[1] = s[1] + s[3] * sinf(s[4]) * DT;                  // :361
+  float sn, cs;
+  sincos_fast(s[4], sn, cs);
+  s[0] = s[0] + s[3] * cs * DT;                          // :360
+  s[1] = s[1] + s[3] * sn * DT;                          // :361
   s[2] = clipf(s[2] + dv * DT, -SMAX, SMAX);             // :362-363
   s[3] = clipf(s[3] + a * DT, VMIN, VMAX);               // :364-365
-  s[4] = s[4] + (s[3] / WB) * tanf(s[2]) * DT;           // :366
+  s[4] = s[4] + (s[3] / WB) * tan_fast(s[2]) * DT;       // :366
 }
 
 // Frenet model, low-speed RHS only, src/irbfn_mpc/dynamics.py:190-281 (:267-280).
@@ -73,10 +114,11 @@ __device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_
   const float ey = s[1], delta = clipf(s[2], -s_max, s_max), vx = s[3], epsi = s[6], cur = s[7];
   const float a = clipf(a_in, -a_max, a_max);            // :235
   const float dv = clipf(dv_in, -sv_max, sv_max);        // :236
-  const float ce = cosf(epsi);
+  float se, ce;
+  sincos_fast(epsi, se, ce);
   const float d0 = (vx * ce) / (1.0f - ey * cur);        // :268
-  const float d1 = vx * sinf(epsi);                      // :269
-  const float d6 = (vx * tanf(delta)) / (LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
+  const float d1 = vx * se;                              // :269
+  const float d6 = (vx * tan_fast(delta)) / (LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
   s[0] = s[0] + d0 * dt;
   s[1] = s[1] + d1 * dt;
   s[2] = s[2] + dv * dt;
@@ -113,8 +155,11 @@ __device__ __forceinline__ void spiral_step(float (&st)[6], const float (&c)[4],
     th = th + temp * sk / (float)(j + 1);
     pw = pw * sk;
   }
-  const float dx = st[4] * (1.0f - 1.0f / k) + (cosf(th) + cosf(st[2])) / 2.0f / k;   // :47-50
-  const float dy = st[5] * (1.0f - 1.0f / k) + (sinf(th) + sinf(st[2])) / 2.0f / k;   // :51-54
+  float s_new, c_new, s_old, c_old;
+  sincos_fast(th, s_new, c_new);
+  sincos_fast(st[2], s_old, c_old);
+  const float dx = st[4] * (1.0f - 1.0f / k) + (c_new + c_old) / 2.0f / k;   // :47-50
+  const float dy = st[5] * (1.0f - 1.0f / k) + (s_new + s_old) / 2.0f / k;   // :51-54
   st[0] = sk * dx;
   st[1] = sk * dy;
   st[2] = th;

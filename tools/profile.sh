@@ -15,6 +15,8 @@ CMD=("$@")
 pass A SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 pass B SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS GRBM_GUI_ACTIVE
 pass C SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_DATA_READ_REQ SQC_TC_STALL SQC_DCACHE_BUSY_CYCLES
+pass F SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
+pass G TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum
 pass D FETCH_SIZE
 pass E WRITE_SIZE
 find "$OUT" -name "*.csv" | head -40
