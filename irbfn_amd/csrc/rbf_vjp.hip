@@ -20,9 +20,8 @@
 namespace irbfn {
 
 struct VjpArgs {
-  const float* __restrict__ x;      // [B][Dreal]
-  const float* __restrict__ g;      // [B][O]
-  const float* __restrict__ gamma;  // [B][R]
+  const float* __restrict__ qrec;   // [B][QS] packed query records { x[0..D), gamma (R == 1), g[0..OP) }
+  const float* __restrict__ gamma;  // [B][R]  (R > 1: per-lane region weight)
   const float* __restrict__ rec;    // [N][S]
   const float* __restrict__ sig2;   // [N]
   float* __restrict__ part;         // [QSB][V][Npad]
@@ -40,6 +39,42 @@ __device__ __forceinline__ float dphi_dd2(float phi, float gscale, int basis) {
   else return basis == IRBFN_MULTIQUADRIC ? 0.5f / phi : 1.0f;       // sqrt(1+d2) | d2
 }
 
+// Pre-pass: one packed, zero-padded record per query so that the hot loop reads ONE contiguous scalar
+// stream (s_load_dwordx16 + x4) without per-element bounds branches:
+//   qrec[b] = { x[b, 0..D) (padded to DC), gamma[b] (R == 1; model.py:42-95), g[b, 0..O) (padded to OP) }.
+// For R > 1 the full gamma[B][R] matrix is written as well (per-lane region weights).
+__global__ __launch_bounds__(64) void vjp_pack_queries_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              float* __restrict__ qrec, float* __restrict__ gamma,
+                                                              GateTables gt, long B, int D, int DC, int O, int OP,
+                                                              int QS, int R) {
+  extern __shared__ float gtab[];                 // [E][64]
+  const int lane = threadIdx.x;
+  const long b = (long)blockIdx.x * kWave + lane;
+  const long bb = b < B ? b : B - 1;
+  const int E = gt.nsplit * gt.max_ranges;
+  for (int e = 0; e < E; ++e) {
+    const int d = e / gt.max_ranges;
+    gtab[e * kWave + lane] = gate_factor(x[bb * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+  }
+  if (b >= B) return;
+  float* q = qrec + b * QS;
+  for (int j = 0; j < DC; ++j) q[j] = j < D ? x[b * D + j] : 0.0f;
+  float g0 = 0.0f;
+  for (int r = 0; r < R; ++r) {
+    float gm = 0.0f;
+    if (r < gt.n_ranges) {
+      gm = 1.0f;
+      for (int d = 0; d < gt.nsplit; ++d)
+        gm *= gtab[(d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d]) * kWave + lane];
+    }
+    if (r == 0) g0 = gm;
+    if (R > 1) gamma[b * R + r] = gm;
+  }
+  q[DC] = g0;
+  for (int o = 0; o < OP; ++o) q[DC + 1 + o] = o < O ? g[b * O + o] : 0.0f;
+  for (int j = DC + 1 + OP; j < QS; ++j) q[j] = 0.0f;
+}
+
 template <int D, int OP, int BC, bool GATED>
 __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
   extern __shared__ float lds[];
@@ -50,7 +85,6 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.x * kWave + lane;
   const int nn = n < a.N ? n : a.N - 1;
-  const int Dr = a.Dreal, O = a.O;
 
   // this lane's centre
   const float* rp = a.rec + (size_t)nn * a.S;
@@ -69,20 +103,22 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
 #pragma unroll
   for (int o = 0; o < OP; ++o) gw[o] = 0.0f;
 
-  // this wave's query slice
+  // this wave's query slice: records stream through the scalar cache (wave-uniform addresses)
+  constexpr int QS = (D + 1 + OP + 3) & ~3;
   const long slice = (long)blockIdx.y * 4 + wave;
   const long b0 = slice * a.per_wave;
-  long b1 = b0 + a.per_wave;
-  b1 = b1 < a.B ? b1 : a.B;
-  for (long b = b0; b < b1; ++b) {
-    const float* xb = a.x + b * Dr;          // uniform -> SGPRs
-    const float* gb = a.g + b * O;
+  long b1l = b0 + a.per_wave;
+  b1l = b1l < a.B ? b1l : a.B;
+  const int nq = b1l > b0 ? (int)(b1l - b0) : 0;
+  const float* qp = a.qrec + b0 * QS;
+  const float* gmp = a.gamma + b0 * a.R + r;     // GATED only
+#pragma unroll 2
+  for (int i = 0; i < nq; ++i, qp += QS) {
     float diff[D];
     float r2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const float xv = j < Dr ? xb[j < Dr ? j : 0] : 0.0f;
-      diff[j] = xv - c[j];
+      diff[j] = qp[j] - c[j];
       r2 = __builtin_fmaf(diff[j], diff[j], r2);
     }
     const float d2 = r2 * s2;
@@ -90,14 +126,15 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
     if constexpr (BC == BC_GAUSS) phi = fast_exp2(r2 * sc);
     else phi = basis_from_r2<BC>(r2, sc, a.basis);
     float gam;
-    if constexpr (GATED) gam = a.gamma[b * a.R + r];
-    else gam = a.gamma[b];
+    if constexpr (GATED) gam = gmp[(long)i * a.R];
+    else gam = qp[D];
+    const float gphi = gam * phi;
     float hbar = 0.0f;
 #pragma unroll
     for (int o = 0; o < OP; ++o) {
-      const float go = o < O ? gb[o < O ? o : 0] : 0.0f;
+      const float go = qp[D + 1 + o];
       hbar = __builtin_fmaf(go, w[o], hbar);
-      gw[o] = __builtin_fmaf(gam * phi, go, gw[o]);
+      gw[o] = __builtin_fmaf(gphi, go, gw[o]);
     }
     const float t = hbar * gam * dphi_dd2<BC>(phi, a.gscale, a.basis);
     gls = __builtin_fmaf(t, -2.0f * d2, gls);
@@ -182,19 +219,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ g_bias, int nblocks, int O) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= O) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ g_bias,
+                                                            int nblocks, int O) {
+  __shared__ float sm[256];
+  const int o = blockIdx.x, t = threadIdx.x;
   float s = 0.0f;
-  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * O + o];
-  g_bias[o] = s;
+  for (int b = t; b < nblocks; b += 256) s += part[(size_t)b * O + o];
+  sm[t] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {             // fixed tree -> deterministic
+    if (t < w) sm[t] += sm[t + w];
+    __syncthreads();
+  }
+  if (t == 0) g_bias[o] = sm[0];
 }
 
 // ------------------------------------------------------------------------------------------------
 struct VjpPlan {
   int groups, QSB, per_wave, Npad, V, bias_blocks;
   long rows_per_block;
-  size_t off_gamma, off_part, off_bias, total;
+  size_t off_gamma, off_part, off_bias, off_qrec, total;
+  int QS;
 };
 
 static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
@@ -217,9 +262,11 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   p.rows_per_block = (B + p.bias_blocks - 1) / p.bias_blocks;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  p.off_gamma = off; off += al((size_t)B * net->R * sizeof(float));
+  p.off_gamma = off; off += al((size_t)(net->R > 1 ? B * net->R : 1) * sizeof(float));
   p.off_part = off;  off += al((size_t)p.QSB * p.V * p.Npad * sizeof(float));
   p.off_bias = off;  off += al((size_t)p.bias_blocks * net->O * sizeof(float));
+  p.QS = (net->DC + 1 + net->OP + 3) & ~3;
+  p.off_qrec = off;  off += al((size_t)B * p.QS * sizeof(float));
   p.total = off;
   return p;
 }
@@ -296,11 +343,18 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   float* part = reinterpret_cast<float*>(base + p.off_part);
   float* bpart = reinterpret_cast<float*>(base + p.off_bias);
 
-  int rc = launch_gate(net, x, gamma, B, s);      // gamma[B][R] (model.py:42-95)
-  if (rc != IRBFN_OK) return rc;
+  float* qrec = reinterpret_cast<float*>(base + p.off_qrec);
+  {
+    const size_t glds = (size_t)net->nsplit * net->max_ranges * kWave * sizeof(float);
+    if (glds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vjp_pack_queries_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), glds, s, x, gout,
+                       qrec, gamma, net->gate(), (long)B, net->D, net->DC, net->O, net->OP, p.QS, net->R);
+    IRBFN_HIP_CHECK(hipGetLastError());
+  }
+  int rc = IRBFN_OK;
 
   VjpArgs a;
-  a.x = x; a.g = gout; a.gamma = gamma; a.rec = net->rec; a.sig2 = net->sig2; a.part = part;
+  a.qrec = qrec; a.gamma = gamma; a.rec = net->rec; a.sig2 = net->sig2; a.part = part;
   a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.N = net->N; a.K = net->K; a.R = net->R; a.S = net->S;
   a.basis = net->basis; a.Npad = p.Npad; a.per_wave = p.per_wave; a.gscale = gauss_scale(net->basis);
   const dim3 grid(p.groups, p.QSB);
@@ -321,8 +375,7 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
                      (long)B, net->O, p.rows_per_block);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((net->O + 63) / 64), dim3(64), 0, s, bpart, g_bias, p.bias_blocks,
-                     net->O);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
