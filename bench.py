@@ -53,9 +53,16 @@ def dist_setup(n_gpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # rehearsal knobs (one-GPU box): IRBFN_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+        # IRBFN_DIST_BACKEND=gloo avoids RCCL's one-rank-per-device rule; the driver uses neither.
+        dev = 0 if os.environ.get("IRBFN_BENCH_SAME_DEVICE") == "1" else local
+        backend = os.environ.get("IRBFN_DIST_BACKEND", "nccl")
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if world != n_gpus:
@@ -135,9 +142,15 @@ def main():
     flops = B * N * (3 * D + 2 + 2 * O)                          # per pair 3D + 2 + 2O
     abytes = 4 * (B * D + N * D + N + N * O + O + B * O)         # every tensor touched once
     launch = net.last_launch()
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):                      # measured by rocprofv3 PMC passes of this same command
+        rec = json.load(open(tpath)).get(launch["kernel"])
+        if rec:
+            traffic, traffic_src = rec["bytes"], "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, per launch)"
     roofline = {
         "bound": "mfma", "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-        "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+        "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
         "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
         "note": "fp32 kernel: peak = 157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak); the kernel "
