@@ -63,42 +63,51 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kRollWaves = 4;      // waves per workgroup (independent; wave-private LDS)
 constexpr int kRollTS = 4;         // steps staged per flush = controls fetched per 16-byte load
 
-// What makes this kernel fast (each item measured, profiles/r01_rollout_*):
+// What makes this kernel fast (each item measured, profiles/r01_rollout_*, tools/ubench_mem.hip):
 //  * occupancy: one step is a long DEPENDENT chain, so a SIMD needs several resident waves; LDS is
-//    kept to one 64 x 33-float tile per wave (8.4 KB), shared by the input and output staging;
+//    one 64 x 37-float tile per wave (9.5 KB), shared by the input and the output staging;
 //  * straight-line sin/cos/tan (rollout_step.h) instead of ocml's branchy range reduction;
-//  * 16-byte accesses: controls 128 contiguous bytes per stream per lane at a time, states flushed
-//    through the LDS tile as row runs of TS*S floats.
-// Known limit (profiles/r01_rollout_notes.md): the rows are only dword aligned and gfx950 splits
-// unaligned 16-byte accesses, so loads, compute and stores add up instead of overlapping
-// (compute 67 us + loads 72 us + stores 110 us at B = 262144, T = 50); the next step is a
-// sliding-window flush that writes only aligned float4 pieces.
+//  * only ALIGNED 16-byte HBM accesses.  Rows are merely dword aligned and gfx950 splits unaligned
+//    16-byte accesses (112-byte row runs: 2.2 TB/s unaligned float4 vs 4.2 TB/s aligned float2).
+//    - stores: sliding window.  Row r's buffer starts C_r floats before the chunk so that it begins
+//      on a 16-byte boundary of HBM; TS*S = 0 (mod 4), hence every flush emits exactly TS*S/4
+//      aligned float4 per row and carries the same C_r trailing floats into the next chunk; only
+//      the first C_r-complement and the last < 4 floats of a row are written as dwords.
+//    - loads: per 8-step chunk the aligned float4 superset of a[t0..t0+8) (<= 3 pieces per row) is
+//      fetched cooperatively, 21 rows per instruction, all loads of a stream issued back to back.
+//  * the chunk loop stays rolled: fully unrolling 32 steps cost 239 VGPRs (2 waves/SIMD).
 template <int MODE>
 __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const RollArgs a) {
   extern __shared__ float lds[];
   constexpr int S = ModeTraits<MODE>::S;
   constexpr int S0 = ModeTraits<MODE>::S0;
   constexpr int TS = kRollTS;
-  constexpr int TCH = 32;                        // steps per control chunk (128 bytes per stream per row)
-  constexpr int PITCH = 33;                      // >= max(TS*S, TCH), odd: conflict-free row-wise access
+  constexpr int CF = TS * S;                     // floats per full output chunk per row
+  constexpr int NP = CF / 4;                     // aligned float4 pieces per row per flush
+  constexpr int TCH = 32;                        // steps per control chunk
+  constexpr int PITCH = 37;                      // >= max(CF + 3, 4*PPR), odd -> conflict-free row access
+  static_assert(CF % 4 == 0 && CF + 3 <= PITCH && NP <= 8, "sliding-window flush needs TS*S = 0 (mod 4)");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long b0 = ((long)blockIdx.x * kRollWaves + wave) * kWave;
   if (b0 >= a.B) return;                         // whole wave out of range (no block-level barriers used)
   const long left = a.B - b0;
   const int nvalid = left < kWave ? (int)left : kWave;
+  const bool last_tile = left <= kWave;          // reads near the end of the input buffer stay scalar
   const int L = a.L, T = a.T;
   const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
   const float* row = a.x0u + bb * L;
-  static_assert(TS * S <= 32, "output chunk must fit the tile");
-  float* outt = lds + wave * (kWave * PITCH);
-  float* myout = outt + lane * PITCH;
+  float* tile = lds + wave * (kWave * PITCH);
+  float* mine = tile + lane * PITCH;
   auto wave_sync = [&]() {                       // wave-private LDS: in-order queue, no workgroup barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   float* gout = a.states + b0 * (long)T * S;     // tile base in HBM; row stride T*S
+  // leading floats of a row's window that belong to the previous 16-byte block: C = (addr / 4) mod 4
+  auto carry_of = [&](int r) { return (int)((reinterpret_cast<uintptr_t>(gout + (long)r * T * S) >> 2) & 3); };
+  const int myC = carry_of(lane < nvalid ? lane : 0);
 
   float s[S];
   [[maybe_unused]] float coef[4];
@@ -118,38 +127,103 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
     for (int i = 0; i < S; ++i) s[i] = row[i];
   }
 
-  // Controls: each lane streams its own row, 128 contiguous bytes per stream at a time (TCH = 32
-  // steps = 8 x 16-byte loads per stream, all issued back to back -> one wait per chunk).
+  // cooperative aligned fetch of one control stream chunk: floats [g0, g0 + n) of every row, g0 = r*L + off
+  auto fetch_stream = [&](int off, int n, float (&dst)[TCH]) {
+    if (last_tile || (a.dbg & 2)) {              // scalar path (tail tile / diagnosis)
+#pragma unroll
+      for (int i = 0; i < TCH; ++i) dst[i] = (a.dbg & 2) ? 0.25f : (i < n ? row[off + i] : 0.0f);
+      return;
+    }
+    const float* tin = a.x0u + b0 * L;
+    constexpr int PPR = (TCH + 3 + 3) / 4, RPI = kWave / PPR, NI = (kWave + RPI - 1) / RPI;   // pieces/row, rows/instr
+    const int rsub = lane / PPR, part = lane - rsub * PPR;
+    float4 v[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {               // all loads first: one wait for the whole stream chunk
+      int r = j * RPI + rsub;
+      r = (r < nvalid && rsub < RPI) ? r : 0;
+      const float* g0 = tin + (long)r * L + off;
+      const float* al = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(g0) & ~(uintptr_t)15);
+      v[j] = *reinterpret_cast<const float4*>(al + 4 * part);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = j * RPI + rsub;
+      if (r < nvalid && rsub < RPI) {
+        float* t = tile + r * PITCH + 4 * part;
+        t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
+      }
+    }
+    wave_sync();
+    const int sh = (int)((reinterpret_cast<uintptr_t>(row + off) >> 2) & 3);   // my row's offset inside piece 0
+#pragma unroll
+    for (int i = 0; i < TCH; ++i) dst[i] = i < n ? mine[sh + i] : 0.0f;
+    wave_sync();
+  };
+
+  // cooperative flush of the row windows: pieces [4p, 4p+4) of each row's buffer -> aligned float4 in HBM
+  auto flush = [&](int t0, bool first) {
+    const int rsub = lane >> 3, part = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                // 8 x (4 LDS reads + 1 aligned 16-byte store)
+      const int r = j * 8 + rsub;
+      if (r < nvalid && part < NP) {
+        const int C = carry_of(r);
+        const float* src = tile + r * PITCH + 4 * part;
+        float* dst = gout + (long)r * T * S + (long)t0 * S - C + 4 * part;     // 16-byte aligned
+        if (a.dbg & 1) continue;
+        if (first && part == 0 && C > 0) {       // the window starts before the row: only floats [C, 4) exist
+          for (int i = C; i < 4; ++i) dst[i] = src[i];
+        } else {
+          *reinterpret_cast<float4*>(dst) = float4{src[0], src[1], src[2], src[3]};
+        }
+      }
+    }
+  };
+
+  int fill = myC;                                // floats in my window (the first C are carry / padding)
+#pragma unroll 1
   for (int tc = 0; tc < T; tc += TCH) {
     float ua[TCH], us[TCH];
     if constexpr (MODE != IRBFN_ROLLOUT_SPIRAL) {
+      const int n = (T - tc) < TCH ? (T - tc) : TCH;
+      // the carry lives in the tile: park it in registers while the tile stages the controls
+      float keep[3];
 #pragma unroll
-      for (int i4 = 0; i4 < TCH / 4; ++i4) {
-        const int t = tc + 4 * i4;
-        if (a.dbg & 2) {
+      for (int i = 0; i < 3; ++i) keep[i] = mine[i];
+      wave_sync();
+      fetch_stream(S0 + tc, n, ua);              // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
+      fetch_stream(S0 + T + tc, n, us);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { ua[4 * i4 + i] = 0.5f; us[4 * i4 + i] = 0.1f; }
-        } else if (t + 3 < T) {                  // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
-          const f4u va = *reinterpret_cast<const f4u*>(row + S0 + t);
-          const f4u vs = *reinterpret_cast<const f4u*>(row + S0 + T + t);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { ua[4 * i4 + i] = va[i]; us[4 * i4 + i] = vs[i]; }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            ua[4 * i4 + i] = (t + i) < T ? row[S0 + t + i] : 0.0f;
-            us[4 * i4 + i] = (t + i) < T ? row[S0 + T + t + i] : 0.0f;
-          }
-        }
-      }
+      for (int i = 0; i < 3; ++i) mine[i] = keep[i];
     }
 #pragma unroll
     for (int ts = 0; ts < TCH; ts += TS) {
       const int t0 = tc + ts;
-      if (t0 < T) {
-        const int tn = (T - t0) < TS ? (T - t0) : TS;
+      if (t0 + TS <= T) {                        // full chunk
 #pragma unroll
         for (int tt = 0; tt < TS; ++tt) {
+          if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[ts + tt], us[ts + tt], a.dp);
+          else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[ts + tt], us[ts + tt], a.dp);
+          else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[ts + tt], us[ts + tt]);
+          else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[ts + tt], us[ts + tt], a.dp);
+          else spiral_step(s, coef, slen, t0 + tt, T);
+#pragma unroll
+          for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
+        }
+        wave_sync();
+        flush(t0, t0 == 0);
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {            // carry the last C floats to the front of the window
+          const float v = mine[CF + i];
+          if (i < myC) mine[i] = v;
+        }
+        fill = myC;
+      } else if (t0 < T) {                       // partial last chunk: dword stores
+        const int tn = T - t0;
+#pragma unroll
+        for (int tt = 0; tt < TS - 1; ++tt) {      // static register indices (no scratch)
           if (tt < tn) {
             if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[ts + tt], us[ts + tt], a.dp);
             else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[ts + tt], us[ts + tt], a.dp);
@@ -157,39 +231,20 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
             else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[ts + tt], us[ts + tt], a.dp);
             else spiral_step(s, coef, slen, t0 + tt, T);
 #pragma unroll
-            for (int i = 0; i < S; ++i) myout[tt * S + i] = s[i];
+            for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
           }
         }
-        wave_sync();
-        // flush: row r, run [t0*S, t0*S + tn*S) -> contiguous tn*S floats at gout + r*T*S + t0*S, as
-        // 16-byte pieces (TS*S/4 lanes per row, RPI rows per store instruction).
-        constexpr int P4 = (TS * S) / 4;
-        constexpr int RPI = kWave / P4;
-        if (tn == TS) {
-          const int rsub = lane / P4, part = lane - rsub * P4;
-          if (rsub < RPI) {
-#pragma unroll
-            for (int j = 0; j < (kWave + RPI - 1) / RPI; ++j) {
-              const int r = j * RPI + rsub;
-              if (r < nvalid) {
-                const float* src = outt + r * PITCH + 4 * part;
-                f4u v;
-                v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
-                if (!(a.dbg & 1) || v[0] == 12345.678f)
-                  *reinterpret_cast<f4u*>(gout + (long)r * T * S + t0 * S + 4 * part) = v;
-              }
-            }
-          }
-        } else {
-          const int seg = tn * S;
-          for (int idx = lane; idx < nvalid * seg; idx += kWave) {
-            const int r = idx / seg, c = idx - r * seg;
-            gout[(long)r * T * S + t0 * S + c] = outt[r * PITCH + c];
-          }
-        }
-        wave_sync();
+        fill = myC + tn * S;
       }
     }
+  }
+  // epilogue: whatever is left in my window (carry, or carry + partial chunk) goes out as dwords
+  if (lane < nvalid && !(a.dbg & 1)) {
+    const int done = (T / TS) * TS;              // steps covered by full chunks
+    const int first_unflushed = done * S - (done > 0 ? myC : 0);
+    const int skip = done > 0 ? 0 : myC;         // no full chunk was flushed: window still has its padding
+    float* dst = gout + (long)lane * T * S + first_unflushed;
+    for (int i = skip; i < fill; ++i) dst[i - skip] = mine[i];
   }
 }
 
@@ -197,7 +252,7 @@ template <int MODE>
 static int launch_mode(const RollArgs& a, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
   (void)S;
-  const size_t lds = (size_t)kRollWaves * kWave * 33 * sizeof(float);
+  const size_t lds = (size_t)kRollWaves * kWave * 37 * sizeof(float);
   const long waves = (a.B + kWave - 1) / kWave;
   const long grid = (waves + kRollWaves - 1) / kRollWaves;
   hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
