@@ -80,8 +80,9 @@ typedef enum irbfn_rollout_mode {
  *
  * Compiled kernel set: D in 1..8; any O >= 1 (O is padded internally to a compiled width);
  * R*K >= 1; nsplit <= 8.  Outside it: IRBFN_ERR_UNSUPPORTED.
- * The descriptor owns device buffers for the packed centre records and the gate tables; it is
- * immutable between irbfn_net_set_params calls and may be shared by host threads.
+ * The descriptor owns device buffers for the packed centre records, the gate tables and a small
+ * scratch area of the small-batch latency kernel; calls that use the same descriptor must be ordered
+ * on one stream (or serialised by the caller) -- use one descriptor per concurrent stream.
  */
 typedef struct irbfn_net irbfn_net;
 

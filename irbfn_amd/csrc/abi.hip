@@ -79,6 +79,9 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   alloc((void**)&net->sig2, (size_t)net->N * sizeof(float));
   net->Npad = (net->N + 15) & ~15;
   if (mfma_eligible(net)) alloc((void**)&net->recm, (size_t)net->Npad * mfma_record_floats(D, O) * sizeof(float));
+  alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
+  alloc((void**)&net->small_ticket, 64 * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(net->small_ticket, 0, 64 * sizeof(unsigned int));
   alloc((void**)&net->gate_lo, tab * sizeof(float));
   alloc((void**)&net->gate_hi, tab * sizeof(float));
   alloc((void**)&net->gate_delta, (size_t)(nsplit > 0 ? nsplit : 1) * sizeof(float));
@@ -103,7 +106,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
 
 int irbfn_net_destroy(irbfn_net* net) {
   if (!net) return IRBFN_OK;
-  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete net;

@@ -68,6 +68,8 @@ struct irbfn_net {
   float* sig2;  // [N]      exp(-2 log_sig) (device) -- VJP
   float* recm;  // [Npad][CW + 16*NT] records of the MFMA forward (K1m); NULL if not eligible
   int Npad;     // N rounded up to a multiple of 16 (MFMA chunk)
+  float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
+  unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs
   float* gate_lo;
   float* gate_hi;
@@ -93,6 +95,9 @@ size_t mfma_record_floats(int D, int O);
 int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
                      hipStream_t s);
 int launch_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, int QJ, int nw, hipStream_t s);
+size_t small_workspace_floats(int OP);
+bool small_eligible(const irbfn_net* net, int64_t B);
+int launch_forward_small(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
 int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStream_t s);
 int64_t vjp_workspace_bytes(const irbfn_net* net, int64_t B);
 int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_centers, float* g_log_sigs,

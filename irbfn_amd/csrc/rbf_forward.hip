@@ -210,6 +210,11 @@ static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t 
 
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (B == 0) return IRBFN_OK;
+  // K1s: small batches (planner ticks) -> centre-lane latency kernel; IRBFN_FWD_SMALL=0 forces K1
+  if (small_eligible(net, B) && env_int("IRBFN_FWD_SMALL", 1) != 0) {
+    const int rc = launch_forward_small(net, x, out, B, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
   if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
   FwdArgs a;
   fill_args(net, a, x, out, B);

@@ -81,6 +81,27 @@ def test_forward_trained_checkpoints(gpu, run):
     np.testing.assert_allclose(gam, gamma64, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("run", CKPT_RUNS)
+def test_small_batch_kernel_and_tiled_kernel_agree(gpu, run, monkeypatch):
+    """B <= 64 dispatches to the centre-lane latency kernel (K1s); IRBFN_FWD_SMALL=0 forces the tiled
+    query-lane kernel (K1, incl. its gated R > 1 path).  Both must meet the oracle and each other."""
+    cfg, params, x, out64, h64, _ = load_ckpt_fixture(run)
+    net = WCRBFNet.from_config(cfg)
+    x32 = x.astype(np.float32)
+    a = net.apply(params, x32)
+    assert "clane" in net.last_launch()["kernel"]
+    one = net.apply(params, x32[:1])                          # the planner's B = 1 call
+    np.testing.assert_array_equal(one, net.apply(params, x32[:1]))   # fixed-order reduction: deterministic
+    monkeypatch.setenv("IRBFN_FWD_SMALL", "0")
+    b = net.apply(params, x32)
+    assert "qlane" in net.last_launch()["kernel"]
+    scale = np.abs(h64) @ np.abs(np.asarray(params["params"]["linear"]["kernel"], np.float64))
+    for out in (a, b):
+        assert (np.abs(out - out64) <= RTOL * np.abs(out64) + 3e-6 * scale).all()
+    assert (np.abs(a - b) <= 4e-6 * scale + 1e-6).all()
+    assert (np.abs(one - a[:1]) <= 4e-6 * scale[:1] + 1e-6).all()
+
+
 def test_forward_cfg1_fixture(gpu):
     import os
     from conftest import GOLDEN
