@@ -232,6 +232,14 @@ def run_extras(net, params, x, configs, torch):
     g = torch.from_numpy(configs.synth_cotangent(3)).cuda()
     t = _time(lambda: (net(x), net.vjp(params, x, g)), 20, torch)
     out["cfg3_fwd_plus_vjp"] = {"evals_per_s": B / t, "ms": t * 1e3, "batch": B}
+    # full training step (scripts/train_nmpc.py:258-300): forward + loss/seeds + VJP + clip/Adam, on device
+    from irbfn_amd import train
+    state = train.TrainState.create(net, configs.synth_params(3), lr=1e-3, max_grad_norm=1.0)
+    yt = torch.from_numpy(configs.synth_cotangent(3)).cuda()
+    t = _time(lambda: train.train_step_oneint(state, x, yt, configs.DYN_PARAMS), 20, torch)
+    out["cfg3_train_step_oneint"] = {"evals_per_s": B / t, "ms": t * 1e3, "batch": B,
+                                     "what": "fwd + loss seeds + param VJP + clip_by_global_norm + adam, no host sync"}
+    net.bind(params)
     # roll-out: 32768 trajectories (cfg-4 per-GPU share), T = 50, kinematic single track
     Bt, T = 32768, 50
     st0 = configs.initial_state_from_query(x[:Bt].cpu().numpy())

@@ -150,6 +150,33 @@ int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, cons
                               const float* dyn_params_host, float* controls_dev, float* states_dev,
                               int64_t B, int T, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step pieces: the loss compositions that define the VJP seeds, and the
+ * optimiser chain, on device -- a step needs no host round trip (the reference pulls the loss with
+ * jax.device_get every step, scripts/train_nmpc.py:477-479).  Caller-allocated buffers only.
+ *
+ * irbfn_train_seeds_oneint: loss_fn of train_step_oneint (scripts/train_nmpc.py:268-295):
+ *   loss = mean(l2(y_pred, y)) + mean(l2(onestep(x_pred_u)[:, [0,1,3,4]], onestep(x_u)[:, [0,1,3,4]])),
+ *   initial state [0,0,0, x[:,0], 0, x[:,6], x[:,5]] (:260-266), one step = dynamic_st_onestep_aux.
+ *   Writes gy = d loss / d y_pred [B,O] and the scalar loss (device).  D >= 7, O >= 2.
+ * irbfn_train_seeds_fullint: loss_fn of train_step_fullint (scripts/train_nmpc.py:306-390):
+ *   loss = mean|y_pred[:, [0,T]] - y[:, [0,T]]| + mean|final_pred - final_actual| (T-step inline bicycle), O = 2T.
+ * partials_dev: scratch of irbfn_train_loss_partials() floats.
+ * irbfn_adam_clip_step: optax.chain(clip_by_global_norm(max_grad_norm), adam(lr)) + apply_gradients
+ *   (scripts/train_nmpc.py:231-233, :299) on flat float32 buffers of n elements; step_dev is the
+ *   device-resident update count (incremented by the call).  max_grad_norm <= 0 disables clipping.
+ */
+int irbfn_train_loss_partials(void);
+int irbfn_train_seeds_oneint(const float* x_dev, const float* y_pred_dev, const float* y_dev,
+                             const float* dyn_params_host, float clip_tie, float* gy_dev, float* loss_dev,
+                             float* partials_dev, int64_t B, int D, int O, void* stream);
+int irbfn_train_seeds_fullint(const float* x_dev, const float* y_pred_dev, const float* y_dev, float clip_tie,
+                              float* gy_dev, float* loss_dev, float* partials_dev, int64_t B, int D, int T,
+                              void* stream);
+int irbfn_adam_clip_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n,
+                         int* step_dev, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                         float* partials_dev, void* stream);
+
 /* Diagnostics */
 int irbfn_abi_version(void);
 int irbfn_device_count(void);

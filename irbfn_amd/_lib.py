@@ -33,6 +33,10 @@ SIGNATURES = {
     "irbfn_rollout_forward": (_i, [_i, _fp, _fp, _fp, _i64, _i, _vp]),
     "irbfn_rollout_vjp": (_i, [_i, _fp, _fp, _fp, _fp, _i64, _i, _f, _vp]),
     "irbfn_net_forward_rollout": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i64, _i, _vp]),
+    "irbfn_train_loss_partials": (_i, []),
+    "irbfn_train_seeds_oneint": (_i, [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
+    "irbfn_train_seeds_fullint": (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
+    "irbfn_adam_clip_step": (_i, [_fp, _fp, _fp, _fp, _i64, _vp, _f, _f, _f, _f, _f, _fp, _vp]),
     "irbfn_abi_version": (_i, []),
     "irbfn_device_count": (_i, []),
     "irbfn_last_hip_error": (_i, []),

@@ -36,6 +36,7 @@ UNITS = [
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rollout.hip", "rollout.o", []),
     ("rollout_vjp.hip", "rollout_vjp.o", []),
+    ("train_step.hip", "train_step.o", []),
 ]
 
 

@@ -93,6 +93,7 @@ class WCRBFNet:
         self._handles: Dict[int, C.c_void_p] = {}
         self._bound_fp: Dict[int, tuple] = {}
         self._keepalive: Dict[int, tuple] = {}
+        self._vjp_ws: Dict[int, Any] = {}
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -237,7 +238,7 @@ class WCRBFNet:
         return like_input(g, x, torch)
 
     # ------------------------------------------------------------------ backward
-    def vjp(self, params: dict, x, gout) -> dict:
+    def vjp(self, params: dict, x, gout, out: Optional[dict] = None) -> dict:
         """Parameter VJP: cotangent gout[B,O] -> gradient pytree (same structure as ``params``).
         Replaces ``jax.value_and_grad(loss_fn)(params)`` restricted to the network
         (scripts/train_nmpc.py:297-298).  Gradients w.r.t. x are never taken by the reference."""
@@ -250,17 +251,27 @@ class WCRBFNet:
             raise ValueError(f"gout must have shape ({B}, {self.out_features}), got {tuple(gd.shape)}")
         R, K, D, O = self.num_regions, self.num_kernels, self.in_features, self.out_features
         dev = xd.device
-        gc = torch.empty((R, K, D), dtype=torch.float32, device=dev)
-        gl = torch.empty((R, K), dtype=torch.float32, device=dev)
-        gk = torch.empty((K, O), dtype=torch.float32, device=dev)
-        gb = torch.empty((O,), dtype=torch.float32, device=dev)
+        if out is not None:      # caller-provided gradient leaves (e.g. views of one flat buffer)
+            o = _inner(out)
+            gc, gl, gk, gb = o["rbf_list"]["centers"], o["rbf_list"]["log_sigs"], o["linear"]["kernel"], o["linear"]["bias"]
+            for t, shp in ((gc, (R, K, D)), (gl, (R, K)), (gk, (K, O)), (gb, (O,))):
+                if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                    raise ValueError("vjp out= leaves must be contiguous float32 cuda tensors of the parameter shapes")
+        else:
+            gc = torch.empty((R, K, D), dtype=torch.float32, device=dev)
+            gl = torch.empty((R, K), dtype=torch.float32, device=dev)
+            gk = torch.empty((K, O), dtype=torch.float32, device=dev)
+            gb = torch.empty((O,), dtype=torch.float32, device=dev)
         h = self._handle(torch)
         nbytes = int(lib.irbfn_net_vjp_workspace_bytes(h, B))
-        ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+        ws = self._vjp_ws.get(dev.index)
+        if ws is None or ws.numel() < nbytes:        # grown on demand, reused across steps
+            ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+            self._vjp_ws[dev.index] = ws
         st = lib.irbfn_net_vjp(h, _ptr(xd), _ptr(gd), _ptr(gc), _ptr(gl), _ptr(gk), _ptr(gb), B, _ptr(ws), nbytes,
                                _stream_ptr(torch))
         _lib.check(st, "irbfn_net_vjp")
-        conv = (lambda t: like_input(t, x, torch))
+        conv = (lambda t: t) if out is not None else (lambda t: like_input(t, x, torch))
         return {"params": {"rbf_list": {"centers": conv(gc), "log_sigs": conv(gl)},
                            "linear": {"kernel": conv(gk), "bias": conv(gb)}}}
 

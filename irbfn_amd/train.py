@@ -1,0 +1,98 @@
+"""Training step on device: the counterparts of ``train_step_oneint`` /
+``train_step_fullint`` (scripts/train_nmpc.py:258-300, :303-421) with
+``optax.chain(clip_by_global_norm(max_grad_norm), adam(lr))`` (scripts/train_nmpc.py:231-233).
+
+One step = fused forward (K1) -> loss/seed kernel -> parameter VJP (K2) -> [one all-reduce of the flat
+gradient buffer when torch.distributed is initialised] -> clip + Adam kernel.  Parameters, Adam
+moments and gradients live in ONE flat float32 buffer each (the pytree leaves are views), the step
+count and the loss stay on the device: no host synchronisation per step (the reference does a
+``jax.device_get`` per step, scripts/train_nmpc.py:477-479).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib, distributed
+from .dynamics import _dyn
+from .model import WCRBFNet, _ptr, _stream_ptr, to_device_f32
+
+
+class TrainState:
+    """Stand-in of ``flax.training.train_state.TrainState`` for the hot path: ``params`` (pytree of views
+    into a flat buffer), Adam moments, device-resident step count."""
+
+    def __init__(self, net: WCRBFNet, flat, lr, max_grad_norm, b1, b2, eps):
+        import torch
+        self.net = net
+        self.flat = flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.g = torch.zeros_like(flat)
+        self.step = torch.zeros(1, dtype=torch.int32, device=flat.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.partials = torch.zeros(_lib.load().irbfn_train_loss_partials(), dtype=torch.float32, device=flat.device)
+        self.lr, self.max_grad_norm, self.b1, self.b2, self.eps = float(lr), float(max_grad_norm), float(b1), float(b2), float(eps)
+        self.params = distributed.unflatten_params(net, self.flat)
+        self.grads = distributed.unflatten_params(net, self.g)
+        self.apply_fn = net.apply
+
+    @classmethod
+    def create(cls, net: WCRBFNet, params: dict, lr: float = 1e-3, max_grad_norm: float = 1.0,
+               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> "TrainState":
+        _lib.require_gpu()
+        flat = distributed.flatten_params(distributed.params_to_device(params)).clone()
+        return cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+
+
+def _backward_and_update(state: TrainState, x, gy, torch, lib):
+    state.net.vjp(state.params, x, gy, out=state.grads)
+    if distributed.is_dist() and torch.distributed.get_world_size() > 1:
+        # every rank normalised its seeds by its local batch: global-mean gradient = mean of the partials
+        torch.distributed.all_reduce(state.g, op=torch.distributed.ReduceOp.SUM)
+        state.g.div_(torch.distributed.get_world_size())
+    st = lib.irbfn_adam_clip_step(_ptr(state.flat), _ptr(state.g), _ptr(state.m), _ptr(state.v), state.flat.numel(),
+                                  _ptr(state.step), state.lr, state.b1, state.b2, state.eps, state.max_grad_norm,
+                                  _ptr(state.partials), _stream_ptr(torch))
+    _lib.check(st, "irbfn_adam_clip_step")
+    # the parameter leaves were updated in place behind torch's back: re-bind on the next apply
+    state.net._bound_fp.pop(torch.cuda.current_device(), None)
+
+
+def train_step_oneint(state: TrainState, x, y, dyn_params, clip_tie: float = 0.5) -> Tuple[TrainState, "object"]:
+    """scripts/train_nmpc.py:258-300.  x [B,7], y [B,O>=2] device tensors -> (state, loss[1] on device)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    xd, yd = to_device_f32(x, torch), to_device_f32(y, torch)
+    B, O = yd.shape
+    if xd.shape[1] < 7 or O != state.net.out_features or O < 2:
+        raise ValueError("train_step_oneint needs x [B,7] and y [B,out_features >= 2]")
+    y_pred = state.net.apply(state.params, xd)
+    gy = torch.empty_like(y_pred)
+    keep, pp = _dyn(dyn_params)
+    st = lib.irbfn_train_seeds_oneint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy), _ptr(state.loss),
+                                      _ptr(state.partials), B, xd.shape[1], O, _stream_ptr(torch))
+    _lib.check(st, "irbfn_train_seeds_oneint")
+    loss = state.loss.clone()
+    _backward_and_update(state, xd, gy, torch, lib)
+    return state, loss
+
+
+def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[TrainState, "object"]:
+    """scripts/train_nmpc.py:303-421.  x [B,D], y [B,2T] -> (state, loss[1] on device)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    xd, yd = to_device_f32(x, torch), to_device_f32(y, torch)
+    B, O = yd.shape
+    if O != state.net.out_features or O % 2:
+        raise ValueError("train_step_fullint needs y [B, out_features = 2T]")
+    y_pred = state.net.apply(state.params, xd)
+    gy = torch.empty_like(y_pred)
+    st = lib.irbfn_train_seeds_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), float(clip_tie), _ptr(gy), _ptr(state.loss),
+                                       _ptr(state.partials), B, xd.shape[1], O // 2, _stream_ptr(torch))
+    _lib.check(st, "irbfn_train_seeds_fullint")
+    loss = state.loss.clone()
+    _backward_and_update(state, xd, gy, torch, lib)
+    return state, loss

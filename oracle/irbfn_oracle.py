@@ -595,6 +595,35 @@ def train_oneint_loss(cfg, params, x, y, dyn_params):
     return l2_loss(y_pred, y).mean() + l2_loss(pred[:, idx], actual[:, idx]).mean()  # :286-292
 
 
+def train_fullint_loss(cfg, params, x, y):
+    """scripts/train_nmpc.py:303-390 -- loss of train_step_fullint: L1 on the first accel / steer-vel
+    outputs + L1 on the final state of the 5-step inline bicycle (the middle term is identically 0)."""
+    xp = _ns(x)
+    T = y.shape[1] // 2
+    y_pred = wcrbfnet_apply(cfg, params, x)                                    # :313
+    fin_a = rollout_fullint(x[:, 0], y)[:, -1]                                 # :329-347
+    fin_p = rollout_fullint(x[:, 0], y_pred)[:, -1]                            # :356-374
+    cols = [0, T]
+    absf = np.abs if xp is _NP else (lambda t: t.abs())
+    return absf(y_pred[:, cols] - y[:, cols]).mean() + absf(fin_p - fin_a).mean()   # :386-390
+
+
+def clip_by_global_norm(grads_flat: np.ndarray, max_norm: float) -> np.ndarray:
+    """optax.clip_by_global_norm (third-party, version un-pinned by pyproject.toml:7 -- parity unpinned):
+    g if ||g|| < max_norm else g / ||g|| * max_norm."""
+    gn = np.sqrt((grads_flat.astype(np.float64) ** 2).sum())
+    return grads_flat if gn < max_norm else grads_flat / gn * max_norm
+
+
+def adam_update(p, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    """optax.adam = scale_by_adam(b1, b2, eps, eps_root=0) then scale(-lr); t = incremented count.
+    (Published algorithm of optax; parity unpinned for the same reason.)"""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    mhat, vhat = m / (1 - b1 ** t), v / (1 - b2 ** t)
+    return p - lr * mhat / (np.sqrt(vhat) + eps), m, v
+
+
 # --------------------------------------------------------------------------
 # helpers for tests / fixtures
 # --------------------------------------------------------------------------

@@ -1,0 +1,106 @@
+"""GPU parity of the on-device training step against the oracle: loss value, seeds /
+parameter gradients (torch.autograd of the restatement = the reference's jax.value_and_grad) and
+the optax-style clip + Adam update, for train_step_oneint and train_step_fullint."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_ckpt_fixture
+from irbfn_amd import configs, distributed, train
+from irbfn_amd.model import WCRBFNet
+from oracle import irbfn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DP = np.array(configs.DYN_PARAMS)
+LEAVES = (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias"))
+
+
+def _flat(p):
+    p = p["params"]
+    return np.concatenate([np.asarray(p[g][n], np.float64).reshape(-1) for g, n in LEAVES])
+
+
+def _oracle_step(cfg, params, x, y, loss_fn, lr, max_norm, m, v, t):
+    tp = orc.torch_params(params, torch.float64, requires_grad=True)
+    loss = loss_fn(tp)
+    loss.backward()
+    g = np.concatenate([tp["params"][g_][n].grad.numpy().reshape(-1) for g_, n in LEAVES])
+    gc = orc.clip_by_global_norm(g, max_norm)
+    p_new, m, v = orc.adam_update(_flat(params), gc, m, v, t, lr=lr)
+    return float(loss), g, p_new, m, v
+
+
+def _unflat(net, flat):
+    return {"params": {k: {n: t.numpy() for n, t in d.items()}
+                       for k, d in distributed.unflatten_params(net, torch.from_numpy(flat))["params"].items()}}
+
+
+@pytest.mark.parametrize("max_norm", [1.0, 1e-3])
+def test_train_step_oneint_two_steps(gpu, max_norm):
+    cfg, params, x, *_ = load_ckpt_fixture("dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq")
+    params = orc.cast_params(params, np.float32)
+    y = np.random.default_rng(2).normal(size=(64, 2)).astype(np.float32)
+    x32 = x.astype(np.float32)
+    net = WCRBFNet.from_config(cfg)
+    state = train.TrainState.create(net, params, lr=1e-3, max_grad_norm=max_norm)
+    n = state.flat.numel()
+    m, v = np.zeros(n), np.zeros(n)
+    cur = orc.cast_params(params, np.float64)
+    for t in (1, 2):
+        loss_ref, g_ref, p_ref, m, v = _oracle_step(
+            cfg, cur, x32, y, lambda tp: orc.train_oneint_loss(cfg, tp, torch.tensor(x32, dtype=torch.float64),
+                                                               torch.tensor(y, dtype=torch.float64), DP),
+            1e-3, max_norm, m, v, t)
+        state, loss = train.train_step_oneint(state, torch.from_numpy(x32).cuda(), torch.from_numpy(y).cuda(), DP)
+        assert abs(float(loss) - loss_ref) <= 3e-5 * abs(loss_ref)
+        g_gpu = state.g.cpu().numpy()
+        assert np.abs(g_gpu - g_ref).max() <= 2e-4 * np.abs(g_ref).max()
+        p_gpu = state.flat.cpu().numpy()
+        # Adam's first steps move every parameter by ~lr regardless of the gradient scale
+        assert np.abs(p_gpu - p_ref).max() <= 2e-5 + 1e-6 * np.abs(p_ref).max()
+        assert int(state.step.item()) == t
+        cur = _unflat(net, p_ref)
+    # the updated parameters are what the next forward uses
+    out = net.apply(state.params, torch.from_numpy(x32).cuda()).cpu().numpy()
+    ref = orc.wcrbfnet_apply(cfg, cur, x32.astype(np.float64))
+    assert np.abs(out - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+def test_train_step_fullint(gpu):
+    rng = np.random.default_rng(5)
+    cfg = dict(configs.model_card(2), num_kernels=300, out_features=10)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(-1, 8, size=(1, 300, 7)).astype(np.float32),
+                                      "log_sigs": rng.uniform(0, 2, size=(1, 300)).astype(np.float32)},
+                         "linear": {"kernel": (rng.normal(size=(300, 10)) * 0.3).astype(np.float32),
+                                    "bias": np.zeros(10, np.float32)}}}
+    x = configs.synth_queries(2, B=500)
+    y = np.hstack([rng.normal(size=(500, 5)) * 3, rng.normal(size=(500, 5))]).astype(np.float32)
+    net = WCRBFNet.from_config(cfg)
+    state = train.TrainState.create(net, params, lr=1e-3, max_grad_norm=1.0)
+    n = state.flat.numel()
+    loss_ref, g_ref, p_ref, _, _ = _oracle_step(
+        cfg, orc.cast_params(params, np.float64), x, y,
+        lambda tp: orc.train_fullint_loss(cfg, tp, torch.tensor(x, dtype=torch.float64), torch.tensor(y, dtype=torch.float64)),
+        1e-3, 1.0, np.zeros(n), np.zeros(n), 1)
+    state, loss = train.train_step_fullint(state, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    assert abs(float(loss) - loss_ref) <= 3e-5 * abs(loss_ref)
+    g_gpu = state.g.cpu().numpy()
+    assert np.abs(g_gpu - g_ref).max() <= 5e-4 * np.abs(g_ref).max()
+    assert np.abs(state.flat.cpu().numpy() - p_ref).max() <= 5e-5 + 1e-6 * np.abs(p_ref).max()
+
+
+def test_training_reduces_the_loss(gpu):
+    cfg = dict(configs.model_card(2), num_kernels=256, out_features=2)
+    net = WCRBFNet.from_config(cfg)
+    rng = np.random.default_rng(0)
+    params = net.init(seed=3)
+    params["params"]["rbf_list"]["centers"] = rng.uniform(-1, 8, size=(1, 256, 7)).astype(np.float32)
+    x = torch.from_numpy(configs.synth_queries(2, B=4096)).cuda()
+    y = torch.stack([torch.sin(x[:, 1]) * 3.0, torch.cos(x[:, 3])], dim=1).contiguous()
+    state = train.TrainState.create(net, params, lr=1e-2, max_grad_norm=1.0)
+    losses = []
+    for _ in range(60):
+        state, loss = train.train_step_oneint(state, x, y, DP)
+        losses.append(loss)
+    l = torch.cat(losses).cpu().numpy()
+    assert np.isfinite(l).all() and l[-1] < 0.6 * l[0]
