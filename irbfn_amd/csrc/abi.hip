@@ -80,8 +80,8 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   net->Npad = (net->N + 15) & ~15;
   if (mfma_eligible(net)) alloc((void**)&net->recm, (size_t)net->Npad * mfma_record_floats(D, O) * sizeof(float));
   alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
-  alloc((void**)&net->small_ticket, 64 * sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMemset(net->small_ticket, 0, 64 * sizeof(unsigned int));
+  alloc((void**)&net->small_ticket, small_ticket_count() * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(net->small_ticket, 0, small_ticket_count() * sizeof(unsigned int));
   alloc((void**)&net->gate_lo, tab * sizeof(float));
   alloc((void**)&net->gate_hi, tab * sizeof(float));
   alloc((void**)&net->gate_delta, (size_t)(nsplit > 0 ? nsplit : 1) * sizeof(float));

@@ -96,6 +96,7 @@ int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs
                      hipStream_t s);
 int launch_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, int QJ, int nw, hipStream_t s);
 size_t small_workspace_floats(int OP);
+int small_ticket_count();
 bool small_eligible(const irbfn_net* net, int64_t B);
 int launch_forward_small(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
 int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStream_t s);
