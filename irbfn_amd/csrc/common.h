@@ -105,6 +105,9 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
                float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s);
 int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, float* states, int64_t B,
                            int T, hipStream_t s);
+int launch_rollout_forward_split(int mode, const float* state0, const float* controls, const DynParams& dp,
+                                 float* states, int64_t B, int T, hipStream_t s);
+bool prefer_mfma(const irbfn_net* net);
 int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const float* gstates,
                        float* g_x0u, int64_t B, int T, float clip_tie, hipStream_t s);
 int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float* state0,

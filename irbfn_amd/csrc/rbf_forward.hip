@@ -192,12 +192,23 @@ static void fill_args(irbfn_net* net, FwdArgs& a, const float* x, float* out, in
 // SLOWER than K1 (169-217 us vs 152 us): the f32-input MFMA runs at the fp32 vector rate and does not
 // overlap with the VALU distance/basis work, so with O = 10 padded to a 16-wide tile it buys nothing.
 // Kept as the "reduction expressed as a dense GEMM" variant that BASELINE config 5 asks to report.
+// For WIDE outputs (O > 16: e.g. 50-step control sequences, O = 100) the picture flips: the weight FMAs
+// dominate and the MFMA issues them ~1.8x more densely than SGPR-operand v_fmac (cfg-4 forward 342 ->
+// 301 us), so K1m is the default there.  IRBFN_FWD_MFMA=0/1 forces K1 / K1m.
+bool prefer_mfma(const irbfn_net* net) {
+  const int e = env_int("IRBFN_FWD_MFMA", -1);
+  if (!net->recm || e == 0) return false;
+  return e == 1 || net->O > 16;
+}
+
 static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
-  if (!net->recm || env_int("IRBFN_FWD_MFMA", 0) == 0) return IRBFN_ERR_UNSUPPORTED;
-  int QJ = env_int("IRBFN_FWD_QJ", 4);
-  if (QJ != 1 && QJ != 2 && QJ != 4) QJ = 4;
+  if (!prefer_mfma(net)) return IRBFN_ERR_UNSUPPORTED;
+  const bool wide = net->O > 16;
+  int QJ = env_int("IRBFN_FWD_QJ", wide ? 2 : 4);
+  if (QJ != 1 && QJ != 2 && QJ != 4) QJ = wide ? 2 : 4;
+  if (wide && QJ == 4) QJ = 2;                   // QJ = 4 is compiled for NT <= 4 only
   const long tiles = (B + 16 * QJ - 1) / (16 * QJ);
-  long want = (8192 + tiles - 1) / tiles;
+  long want = ((wide ? 2048 : 8192) + tiles - 1) / tiles;
   int nw = want < 1 ? 1 : (want > 16 ? 16 : (int)want);
   nw = pow2_floor(nw);
   const int chunks = net->Npad / 16;
@@ -229,6 +240,13 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float
       mode != IRBFN_ROLLOUT_FRENET_LS)
     return IRBFN_ERR_UNSUPPORTED;
   if (net->O != 2 * T) return IRBFN_ERR_BAD_ARG;
+  if (controls && prefer_mfma(net) && B > 64) {
+    // wide outputs: K1m forward into the caller's controls buffer, then the roll-out on split rows
+    // (the 2 x B x O x 4 bytes of control traffic are noise next to the B x N x O weight FMAs)
+    int rc = launch_forward(net, x, controls, B, s);
+    if (rc != IRBFN_OK) return rc;
+    return launch_rollout_forward_split(mode, state0, controls, dp, states, B, T, s);
+  }
   if (net->bclass == BC_GENERIC) return IRBFN_ERR_UNSUPPORTED;
   FwdArgs a;
   fill_args(net, a, x, controls, B);

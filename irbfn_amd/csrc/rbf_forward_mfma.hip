@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void rbf_fwd_mfma(const MfmaArgs a) {
 size_t mfma_record_floats(int D, int O) { return (size_t)mfma_cw(D) + 16 * ((O + 15) / 16); }
 
 bool mfma_eligible(const irbfn_net* net) {
-  return net->R == 1 && net->bclass != BC_GENERIC && net->D >= 2 && net->D <= 8 && net->O <= 64;
+  return net->R == 1 && net->bclass != BC_GENERIC && net->D >= 2 && net->D <= 8 && net->O <= 128;
 }
 
 int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
@@ -256,6 +256,8 @@ static int launch_mfma_d(const MfmaArgs& a, int NT, int QJ, int bc, int nw, size
       case 2: return launch_mfma_bc<D, 2, 2>(a, bc, nw, lds, tiles, s);
       case 3: return launch_mfma_bc<D, 3, 2>(a, bc, nw, lds, tiles, s);
       case 4: return launch_mfma_bc<D, 4, 2>(a, bc, nw, lds, tiles, s);
+      case 7: return launch_mfma_bc<D, 7, 2>(a, bc, nw, lds, tiles, s);
+      case 8: return launch_mfma_bc<D, 8, 2>(a, bc, nw, lds, tiles, s);
     }
   } else if (QJ == 1) {
     switch (NT) {
@@ -263,6 +265,8 @@ static int launch_mfma_d(const MfmaArgs& a, int NT, int QJ, int bc, int nw, size
       case 2: return launch_mfma_bc<D, 2, 1>(a, bc, nw, lds, tiles, s);
       case 3: return launch_mfma_bc<D, 3, 1>(a, bc, nw, lds, tiles, s);
       case 4: return launch_mfma_bc<D, 4, 1>(a, bc, nw, lds, tiles, s);
+      case 7: return launch_mfma_bc<D, 7, 1>(a, bc, nw, lds, tiles, s);
+      case 8: return launch_mfma_bc<D, 8, 1>(a, bc, nw, lds, tiles, s);
     }
   }
   return IRBFN_ERR_UNSUPPORTED;

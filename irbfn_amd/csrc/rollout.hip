@@ -48,7 +48,9 @@ template <>
 struct ModeTraits<IRBFN_ROLLOUT_SPIRAL> { static constexpr int S = 6, S0 = 5; };
 
 struct RollArgs {
-  const float* __restrict__ x0u;   // [B][L]
+  const float* __restrict__ x0;    // initial-state rows: row b at x0 + b*L0   (combined layout: x0u, L0 = L)
+  const float* __restrict__ u;     // control rows [a_0.., sv_0..]: row b at u + b*LU (combined: x0u + S0, LU = L)
+  long L0, LU;
   float* __restrict__ states;      // [B][T][S]
   long B;
   int T, L;
@@ -94,9 +96,10 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
   const long left = a.B - b0;
   const int nvalid = left < kWave ? (int)left : kWave;
   const bool last_tile = left <= kWave;          // reads near the end of the input buffer stay scalar
-  const int L = a.L, T = a.T;
+  const int T = a.T;
   const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
-  const float* row = a.x0u + bb * L;
+  const float* row = a.x0 + bb * a.L0;           // initial state (or spiral parameters)
+  const float* urow = a.u + bb * a.LU;           // this lane's controls
   float* tile = lds + wave * (kWave * PITCH);
   float* mine = tile + lane * PITCH;
   auto wave_sync = [&]() {                       // wave-private LDS: in-order queue, no workgroup barrier
@@ -131,10 +134,10 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
   auto fetch_stream = [&](int off, int n, float (&dst)[TCH]) {
     if (last_tile || (a.dbg & 2)) {              // scalar path (tail tile / diagnosis)
 #pragma unroll
-      for (int i = 0; i < TCH; ++i) dst[i] = (a.dbg & 2) ? 0.25f : (i < n ? row[off + i] : 0.0f);
+      for (int i = 0; i < TCH; ++i) dst[i] = (a.dbg & 2) ? 0.25f : (i < n ? urow[off + i] : 0.0f);
       return;
     }
-    const float* tin = a.x0u + b0 * L;
+    const float* tin = a.u + b0 * a.LU;
     constexpr int PPR = (TCH + 3 + 3) / 4, RPI = kWave / PPR, NI = (kWave + RPI - 1) / RPI;   // pieces/row, rows/instr
     const int rsub = lane / PPR, part = lane - rsub * PPR;
     float4 v[NI];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
     for (int j = 0; j < NI; ++j) {               // all loads first: one wait for the whole stream chunk
       int r = j * RPI + rsub;
       r = (r < nvalid && rsub < RPI) ? r : 0;
-      const float* g0 = tin + (long)r * L + off;
+      const float* g0 = tin + (long)r * a.LU + off;
       const float* al = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(g0) & ~(uintptr_t)15);
       v[j] = *reinterpret_cast<const float4*>(al + 4 * part);
     }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
       }
     }
     wave_sync();
-    const int sh = (int)((reinterpret_cast<uintptr_t>(row + off) >> 2) & 3);   // my row's offset inside piece 0
+    const int sh = (int)((reinterpret_cast<uintptr_t>(urow + off) >> 2) & 3);  // my row's offset inside piece 0
 #pragma unroll
     for (int i = 0; i < TCH; ++i) dst[i] = i < n ? mine[sh + i] : 0.0f;
     wave_sync();
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
 #pragma unroll
       for (int i = 0; i < 3; ++i) keep[i] = mine[i];
       wave_sync();
-      fetch_stream(S0 + tc, n, ua);              // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
-      fetch_stream(S0 + T + tc, n, us);
+      fetch_stream(tc, n, ua);                   // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
+      fetch_stream(T + tc, n, us);
 #pragma unroll
       for (int i = 0; i < 3; ++i) mine[i] = keep[i];
     }
@@ -260,17 +263,7 @@ static int launch_mode(const RollArgs& a, hipStream_t s) {
   return IRBFN_OK;
 }
 
-int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, float* states, int64_t B,
-                           int T, hipStream_t s) {
-  if (B == 0 || T == 0) return IRBFN_OK;
-  RollArgs a;
-  a.x0u = x0u;
-  a.states = states;
-  a.B = (long)B;
-  a.T = T;
-  a.L = rollout_input_dim(mode, T);
-  a.dbg = getenv("IRBFN_ROLL_DBG") ? atoi(getenv("IRBFN_ROLL_DBG")) : 0;
-  a.dp = dp;
+static int dispatch_mode(int mode, const RollArgs& a, hipStream_t s) {
   switch (mode) {
     case IRBFN_ROLLOUT_ST_SELECT: return launch_mode<IRBFN_ROLLOUT_ST_SELECT>(a, s);
     case IRBFN_ROLLOUT_ST_KS: return launch_mode<IRBFN_ROLLOUT_ST_KS>(a, s);
@@ -279,6 +272,53 @@ int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, floa
     case IRBFN_ROLLOUT_SPIRAL: return launch_mode<IRBFN_ROLLOUT_SPIRAL>(a, s);
     default: return IRBFN_ERR_BAD_ARG;
   }
+}
+
+static int s0_of(int mode) {
+  switch (mode) {
+    case IRBFN_ROLLOUT_FULLINT: return 1;
+    case IRBFN_ROLLOUT_FRENET_LS: return 8;
+    case IRBFN_ROLLOUT_SPIRAL: return 5;
+    default: return 7;
+  }
+}
+
+// combined layout of the reference: row = [state, a_0..a_{T-1}, sv_0..sv_{T-1}]
+int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, float* states, int64_t B,
+                           int T, hipStream_t s) {
+  if (B == 0 || T == 0) return IRBFN_OK;
+  RollArgs a;
+  a.L = rollout_input_dim(mode, T);
+  a.x0 = x0u;
+  a.u = x0u + s0_of(mode);
+  a.L0 = a.L;
+  a.LU = a.L;
+  a.states = states;
+  a.B = (long)B;
+  a.T = T;
+  a.dbg = getenv("IRBFN_ROLL_DBG") ? atoi(getenv("IRBFN_ROLL_DBG")) : 0;
+  a.dp = dp;
+  return dispatch_mode(mode, a, s);
+}
+
+// split layout: initial states [B][S0] and controls [B][2T] in separate buffers (the planning tick:
+// no hstack((states, pred_u)) copy, src/irbfn_mpc/irbfn_planner.py:209-210)
+int launch_rollout_forward_split(int mode, const float* state0, const float* controls, const DynParams& dp,
+                                 float* states, int64_t B, int T, hipStream_t s) {
+  if (B == 0 || T == 0) return IRBFN_OK;
+  if (mode == IRBFN_ROLLOUT_SPIRAL) return IRBFN_ERR_BAD_ARG;
+  RollArgs a;
+  a.L = rollout_input_dim(mode, T);
+  a.x0 = state0;
+  a.u = controls;
+  a.L0 = s0_of(mode);
+  a.LU = 2L * T;
+  a.states = states;
+  a.B = (long)B;
+  a.T = T;
+  a.dbg = 0;
+  a.dp = dp;
+  return dispatch_mode(mode, a, s);
 }
 
 }  // namespace irbfn
