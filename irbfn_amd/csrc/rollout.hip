@@ -77,7 +77,9 @@ constexpr int kRollTS = 4;         // steps staged per flush = controls fetched 
 //      the first C_r-complement and the last < 4 floats of a row are written as dwords.
 //    - loads: per 8-step chunk the aligned float4 superset of a[t0..t0+8) (<= 3 pieces per row) is
 //      fetched cooperatively, 21 rows per instruction, all loads of a stream issued back to back.
-//  * the chunk loop stays rolled: fully unrolling 32 steps cost 239 VGPRs (2 waves/SIMD).
+//  * measured and rejected: a whole-128-byte-line flush (64-float ring per row, 20 KB LDS per wave):
+//    187-195 us vs 205 us at B = 262144 but 49-54 us vs 40 us at B = 32768 -- the store phase costs
+//    ~100 us whatever the pattern (a 367 MB fill alone takes 64 us), so the simpler window stays.
 template <int MODE>
 __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const RollArgs a) {
   extern __shared__ float lds[];
@@ -255,9 +257,9 @@ template <int MODE>
 static int launch_mode(const RollArgs& a, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
   (void)S;
-  const size_t lds = (size_t)kRollWaves * kWave * 37 * sizeof(float);
   const long waves = (a.B + kWave - 1) / kWave;
   const long grid = (waves + kRollWaves - 1) / kRollWaves;
+  const size_t lds = (size_t)kRollWaves * kWave * 37 * sizeof(float);
   hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
