@@ -177,6 +177,14 @@ int irbfn_adam_clip_step(float* params_dev, const float* grads_dev, float* m_dev
                          int* step_dev, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                          float* partials_dev, void* stream);
 
+/* Dense head of DeeperWCRBFNet (src/irbfn_mpc/model.py:201-289; the model of IRBFNFrenetPlanner with
+ * deeper=True, src/irbfn_mpc/irbfn_planner.py:286-298):  out = linear(relu(linear_pre2(relu(h1)))) with
+ * h1 = linear_pre1(rbf_out) [B,H1] produced by irbfn_net_forward on a descriptor whose Dense layer is
+ * linear_pre1.  w2[H1,H2], b2[H2], w3[H2,O], b3[O] device pointers; H1 = H2 = 64 (hard-coded in the
+ * reference).  Forward only. */
+int irbfn_mlp_head_forward(const float* h1_dev, const float* w2_dev, const float* b2_dev, const float* w3_dev,
+                           const float* b3_dev, float* out_dev, int64_t B, int H1, int H2, int O, void* stream);
+
 /* Diagnostics */
 int irbfn_abi_version(void);
 int irbfn_device_count(void);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "irbfn_train_seeds_oneint": (_i, [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_train_seeds_fullint": (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_adam_clip_step": (_i, [_fp, _fp, _fp, _fp, _i64, _vp, _f, _f, _f, _f, _f, _fp, _vp]),
+    "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),
     "irbfn_abi_version": (_i, []),
     "irbfn_device_count": (_i, []),
     "irbfn_last_hip_error": (_i, []),

@@ -37,6 +37,7 @@ UNITS = [
     ("rollout.hip", "rollout.o", []),
     ("rollout_vjp.hip", "rollout_vjp.o", []),
     ("train_step.hip", "train_step.o", []),
+    ("mlp_head.hip", "mlp_head.o", []),
 ]
 
 

@@ -75,12 +75,15 @@ def restore_checkpoint(ckpt: str) -> Tuple[dict, int]:
             raise FileNotFoundError(f"no checkpoint_<n> file in {ckpt}")
     tree = load_flax_msgpack(path)
     p = tree["params"]["params"] if "params" in tree["params"] else tree["params"]
-    if "rbf_list" not in p or "linear" not in p:
-        raise ValueError(f"{path} does not hold a WCRBFNet parameter tree (found {sorted(p)}): "
-                         "MLP / Deeper / Cluster variants are out of scope")
+    if "rbf_list" not in p or "linear" not in p or "centers" not in p["rbf_list"]:
+        raise ValueError(f"{path} does not hold a WCRBFNet / DeeperWCRBFNet parameter tree (found {sorted(p)}): "
+                         "MLP / Cluster variants are out of scope")
     params = {"params": {
-        "rbf_list": {"centers": np.asarray(p["rbf_list"]["centers"]), "log_sigs": np.asarray(p["rbf_list"]["log_sigs"])},
-        "linear": {"kernel": np.asarray(p["linear"]["kernel"]), "bias": np.asarray(p["linear"]["bias"])}}}
+        "rbf_list": {"centers": np.asarray(p["rbf_list"]["centers"]), "log_sigs": np.asarray(p["rbf_list"]["log_sigs"])}}}
+    # WCRBFNet holds `linear`; DeeperWCRBFNet adds `linear_pre1`, `linear_pre2` (model.py:254-256)
+    for name in ("linear_pre1", "linear_pre2", "linear"):
+        if name in p:
+            params["params"][name] = {"kernel": np.asarray(p[name]["kernel"]), "bias": np.asarray(p[name]["bias"])}
     return params, int(tree.get("step", 0))
 
 
@@ -90,9 +93,11 @@ def save_checkpoint(ckpt_dir: str, params: dict, step: int, prefix: str = "check
 
     def host(a):
         return np.asarray(a.detach().cpu() if hasattr(a, "detach") else a)
-    tree = {"step": int(step), "params": {"params": {
-        "rbf_list": {"centers": host(p["rbf_list"]["centers"]), "log_sigs": host(p["rbf_list"]["log_sigs"])},
-        "linear": {"kernel": host(p["linear"]["kernel"]), "bias": host(p["linear"]["bias"])}}}, "opt_state": {}}
+    inner = {"rbf_list": {"centers": host(p["rbf_list"]["centers"]), "log_sigs": host(p["rbf_list"]["log_sigs"])}}
+    for name in ("linear_pre1", "linear_pre2", "linear"):
+        if name in p:
+            inner[name] = {"kernel": host(p[name]["kernel"]), "bias": host(p[name]["bias"])}
+    tree = {"step": int(step), "params": {"params": inner}, "opt_state": {}}
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, f"{prefix}{step}")
     with open(path, "wb") as f:

@@ -284,6 +284,57 @@ class WCRBFNet:
         return {"kernel": buf.value.decode(), "grid": g.value, "block": b.value}
 
 
+class DeeperWCRBFNet:
+    """``DeeperWCRBFNet`` of the reference (src/irbfn_mpc/model.py:201-289): the RBF stage followed by
+    Dense(64) -> relu -> Dense(64) -> relu -> Dense(out_features).  Parameter pytree (checkpoint layout):
+    ``{"rbf_list": {centers, log_sigs}, "linear_pre1": {kernel[K,64], bias}, "linear_pre2":
+    {kernel[64,64], bias}, "linear": {kernel[64,O], bias}}``.  Forward only: the RBF stage + linear_pre1
+    run in the fused RBF kernel (64-wide Dense), the rest in ``irbfn_mlp_head_forward``."""
+
+    HIDDEN = 64          # model.py:254-255
+
+    def __init__(self, in_features, out_features, num_kernels, basis_func, num_regions, lower_bounds,
+                 upper_bounds, dimension_ranges, activation_idx, delta, **_unused):
+        self.out_features = int(out_features)
+        self.in_features = int(in_features)
+        self.stage = WCRBFNet(in_features=in_features, out_features=self.HIDDEN, num_kernels=num_kernels,
+                              basis_func=basis_func, num_regions=num_regions, lower_bounds=lower_bounds,
+                              upper_bounds=upper_bounds, dimension_ranges=dimension_ranges,
+                              activation_idx=activation_idx, delta=delta)
+        self._fp = None
+        self._head = None
+
+    @classmethod
+    def from_config(cls, cfg) -> "DeeperWCRBFNet":
+        if isinstance(cfg, str):
+            import yaml
+            with open(cfg, "r") as f:
+                cfg = yaml.safe_load(f)
+        elif not isinstance(cfg, dict):
+            cfg = vars(cfg)
+        return cls(**{k: cfg[k] for k in _CFG_FIELDS})
+
+    def apply(self, params: dict, x):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        H, O = self.HIDDEN, self.out_features
+        for name, shp in (("linear_pre2", (H, H)), ("linear", (H, O))):
+            if tuple(p[name]["kernel"].shape) != shp:
+                raise ValueError(f"params {name}.kernel has shape {tuple(p[name]['kernel'].shape)}, expected {shp}")
+        stage_params = {"rbf_list": p["rbf_list"], "linear": p["linear_pre1"]}
+        xd = to_device_f32(x, torch)
+        h1 = self.stage.apply(stage_params, xd)                     # linear_pre1(rbf_out)   model.py:283
+        head = [to_device_f32(a, torch) for a in (p["linear_pre2"]["kernel"], p["linear_pre2"]["bias"],
+                                                  p["linear"]["kernel"], p["linear"]["bias"])]
+        B = xd.shape[0]
+        out = torch.empty((B, O), dtype=torch.float32, device=xd.device)
+        st = lib.irbfn_mlp_head_forward(_ptr(h1), _ptr(head[0]), _ptr(head[1]), _ptr(head[2]), _ptr(head[3]), _ptr(out),
+                                        B, H, H, O, _stream_ptr(torch))
+        _lib.check(st, "irbfn_mlp_head_forward")
+        return like_input(out, x, torch)
+
+
 class _State:
     """Minimal stand-in of flax's TrainState for ``pred_step``: ``apply_fn`` + ``params``."""
 

@@ -260,6 +260,19 @@ def wcrbfnet_apply(cfg: dict, params: dict, x, return_aux: bool = False, chunk: 
     return (out, h, gam) if return_aux else out
 
 
+def deeper_wcrbfnet_apply(cfg: dict, params: dict, x):
+    """DeeperWCRBFNet.__call__ -- src/irbfn_mpc/model.py:259-289 (Dense(64), Dense(64), Dense(O) with
+    relu between, model.py:254-256, 283-287)."""
+    p = params["params"] if "params" in params else params
+    xp = _ns(x)
+    stage = {"rbf_list": p["rbf_list"], "linear": p["linear_pre1"]}
+    stage_cfg = dict(cfg, out_features=p["linear_pre1"]["kernel"].shape[1])
+    out_pre1 = wcrbfnet_apply(stage_cfg, stage, x)                               # :283
+    relu = (lambda t: np.maximum(t, 0)) if xp is _NP else (lambda t: t.clamp(min=0))
+    out_pre2 = relu(out_pre1) @ p["linear_pre2"]["kernel"] + p["linear_pre2"]["bias"]   # :284
+    return relu(out_pre2) @ p["linear"]["kernel"] + p["linear"]["bias"]                 # :285
+
+
 def wcrbfnet_vjp(cfg: dict, params: dict, x: np.ndarray, gout: np.ndarray):
     """Hand-derived VJP of a-4 w.r.t. the parameters, float64 NumPy.
     Only for bases that depend on d^2 alone (gaussian*, inverse_quadratic,

@@ -24,6 +24,19 @@ def load_ckpt_fixture(run):
     return cfg, params, z["x"], z["out64"], z["h64"], z["gamma64"]
 
 
+DEEPER_RUN = "dnmpc_1regions_frenet_l1_bigdata_5stepint_deeper"
+
+
+def load_deeper_fixture(run=DEEPER_RUN):
+    """(cfg, params, x, out64) of the committed DeeperWCRBFNet checkpoint fixture."""
+    z = np.load(os.path.join(GOLDEN, f"ckpt_{run}.npz"))
+    cfg = json.load(open(os.path.join(GOLDEN, f"ckpt_{run}.json")))
+    params = {"params": {k: {n: z[f"{k}__{n}"] for n in names} for k, names in (
+        ("rbf_list", ("centers", "log_sigs")), ("linear_pre1", ("kernel", "bias")),
+        ("linear_pre2", ("kernel", "bias")), ("linear", ("kernel", "bias")))}}
+    return cfg, params, z["x"], z["out64"]
+
+
 CKPT_RUNS = ["dnmpc_1regions_newdata_oldintloss_nomirror_highk", "dnmpc_128regions",
              "dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq", "dnmpc_12regions_frenet_l1_bigdata"]
 

@@ -107,6 +107,27 @@ def ckpt_fixture(run, step):
           float((gam > 1e-3).sum(1).mean()))
 
 
+def deeper_fixture(run="dnmpc_1regions_frenet_l1_bigdata_5stepint_deeper", step=9999):
+    """DeeperWCRBFNet checkpoint (the model of IRBFNFrenetPlanner(deeper=True)) + float64 oracle outputs."""
+    cfg = yaml.safe_load(open(os.path.join(REF, "scripts/configs", run + ".yaml")))
+    cfg = {k: cfg[k] for k in CFG_KEYS if k in cfg}
+    tree = load_flax_msgpack(os.path.join(REF, "scripts/ckpts", run, f"checkpoint_{step}"))
+    p = tree["params"]["params"]
+    params = {"params": {k: {n: np.asarray(v, np.float64) for n, v in p[k].items()}
+                         for k in ("rbf_list", "linear_pre1", "linear_pre2", "linear")}}
+    ns = len(cfg["activation_idx"])
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)])
+    hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    x = np.random.default_rng(123).uniform(lo, hi, size=(64, cfg["in_features"]))
+    out = orc.deeper_wcrbfnet_apply(cfg, params, x)
+    flat = {f"{k}__{n}": np.asarray(p[k][n]) for k in ("rbf_list", "linear_pre1", "linear_pre2", "linear") for n in p[k]}
+    np.savez_compressed(os.path.join(HERE, f"ckpt_{run}.npz"), x=x, out64=out, file_step=np.int64(step),
+                        step=np.int64(tree["step"]), **flat)
+    with open(os.path.join(HERE, f"ckpt_{run}.json"), "w") as f:
+        json.dump(cfg, f)
+    print(run, "out range", float(out.min()), float(out.max()))
+
+
 def synth_cfg1():
     cfg = configs.model_card(1)
     params = configs.synth_params(1, np.float64)
@@ -122,3 +143,4 @@ if __name__ == "__main__":
     for run, step in CKPTS:
         ckpt_fixture(run, step)
     synth_cfg1()
+    deeper_fixture()

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_ckpt_fixture
+from conftest import DEEPER_RUN, load_ckpt_fixture, load_deeper_fixture
 from irbfn_amd import checkpoint, configs
 from irbfn_amd.model import WCRBFNet
 
@@ -44,3 +44,37 @@ def test_reads_reference_checkpoint_and_card():
     assert net.num_regions == 128 and net.basis_func == "inverse_quadratic"
     with pytest.raises(ValueError):       # an MLP checkpoint is not a WCRBFNet tree
         checkpoint.restore_checkpoint(os.path.join(REF, "ckpts", "dnmpc_mlp_512"))
+
+
+def test_deeper_tree_roundtrip_and_oracle(tmp_path):
+    """DeeperWCRBFNet tree (model.py:254-256): save/restore keeps all four sub-trees; the oracle restatement
+    reproduces the committed float64 outputs and reduces to hand-evaluated relu/Dense algebra."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import irbfn_oracle as orc
+    cfg, params, x, out64 = load_deeper_fixture()
+    path = checkpoint.save_checkpoint(str(tmp_path), params, 9999)
+    back, step = checkpoint.restore_checkpoint(path)
+    assert step == 9999 and sorted(back["params"]) == ["linear", "linear_pre1", "linear_pre2", "rbf_list"]
+    for k in back["params"]:
+        for n in back["params"][k]:
+            np.testing.assert_array_equal(back["params"][k][n], params["params"][k][n])
+    p64 = {"params": {k: {n: np.asarray(v, np.float64) for n, v in d.items()} for k, d in params["params"].items()}}
+    got = orc.deeper_wcrbfnet_apply(cfg, p64, x)
+    np.testing.assert_allclose(got, out64, rtol=1e-13, atol=1e-13)
+    # independent algebra: stage net (WCRBFNet with linear_pre1) then two relu/Dense layers
+    q = p64["params"]
+    h1 = orc.wcrbfnet_apply(dict(cfg, out_features=64), {"rbf_list": q["rbf_list"], "linear": q["linear_pre1"]}, x)
+    h2 = np.maximum(h1, 0) @ q["linear_pre2"]["kernel"] + q["linear_pre2"]["bias"]
+    np.testing.assert_allclose(np.maximum(h2, 0) @ q["linear"]["kernel"] + q["linear"]["bias"], out64, rtol=1e-13)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+def test_reads_reference_deeper_checkpoint():
+    params, step = checkpoint.restore_checkpoint(os.path.join(REF, "ckpts", DEEPER_RUN))
+    _, fix, *_ = load_deeper_fixture()
+    from conftest import GOLDEN
+    assert step == int(np.load(os.path.join(GOLDEN, f"ckpt_{DEEPER_RUN}.npz"))["step"]) == 2180000   # optimizer steps
+    for k in ("rbf_list", "linear_pre1", "linear_pre2", "linear"):
+        for n in fix["params"][k]:
+            np.testing.assert_array_equal(params["params"][k][n], fix["params"][k][n])

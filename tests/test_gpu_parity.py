@@ -11,7 +11,7 @@ also required not to exceed the error of a plain float32 CPU evaluation by more 
 import numpy as np
 import pytest
 
-from conftest import CKPT_RUNS, load_ckpt_fixture
+from conftest import CKPT_RUNS, load_ckpt_fixture, load_deeper_fixture
 from irbfn_amd import _lib, configs
 from irbfn_amd import dynamics as dyn
 from irbfn_amd import planner_utils as pu
@@ -524,3 +524,34 @@ def test_autograd_train_step_matches_oracle_grad(gpu):
         a = P["params"][grp][name].grad.cpu().numpy()
         b = tp["params"][grp][name].grad.numpy()
         assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-9, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 64, 333, 4096])
+def test_deeper_wcrbfnet_forward(gpu, B):
+    """DeeperWCRBFNet (model.py:201-289; IRBFNFrenetPlanner(deeper=True)) on the reference's
+    trained checkpoint: fused RBF + linear_pre1 kernel, then the Dense head kernel, vs the float64 oracle."""
+    from irbfn_amd.model import DeeperWCRBFNet
+    cfg, params, x, out64 = load_deeper_fixture()
+    net = DeeperWCRBFNet.from_config(cfg)
+    if B <= x.shape[0]:
+        xs, ref = x[:B], out64[:B]
+    else:
+        ns = len(cfg["activation_idx"])
+        lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+        xs = np.random.default_rng(B).uniform(lo, hi, size=(B, cfg["in_features"])).astype(np.float32).astype(np.float64)
+        p64 = {"params": {k: {n: np.asarray(v, np.float64) for n, v in d.items()} for k, d in params["params"].items()}}
+        ref = orc.deeper_wcrbfnet_apply(cfg, p64, xs)
+    got = net.apply(params, xs.astype(np.float32))
+    assert got.shape == (B, cfg["out_features"]) and got.dtype == np.float32
+    scale = np.abs(ref).max()
+    # float32 path vs float64 oracle on float32-rounded x: 2e-5 of the output scale, or (the trained net's
+    # hidden layer cancels heavily) 4x the error the float32 NumPy restatement itself makes on these rows
+    p32 = {"params": {k: {n: np.asarray(v, np.float32) for n, v in d.items()} for k, d in params["params"].items()}}
+    err32 = np.abs(orc.deeper_wcrbfnet_apply(cfg, p32, xs.astype(np.float32)).astype(np.float64) - ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= max(2e-5 * scale + 1e-5, 4 * err32), (err, err32, scale)
+    # params with a wrong head shape are rejected before any launch
+    bad = {"params": dict(params["params"], linear_pre2={"kernel": np.zeros((64, 32)), "bias": np.zeros(32)})}
+    with pytest.raises(ValueError):
+        net.apply(bad, xs.astype(np.float32))
