@@ -96,3 +96,18 @@ def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[
     loss = state.loss.clone()
     _backward_and_update(state, xd, gy, torch, lib)
     return state, loss
+
+
+def train_epoch(state: TrainState, table, batch_size: int, only_onestep: bool = False, dyn_params=None):
+    """scripts/train_nmpc.py:455-486: one pass over a ``tables.DeviceTable``.  Returns (state, losses [steps]
+    on the device) -- the reference fetches every batch loss to the host (``jax.device_get``, :477-481);
+    here nothing synchronises until the caller reads ``losses``."""
+    torch = _lib.require_gpu()
+    losses = []
+    for bx, by in table.epoch(batch_size):
+        if only_onestep:
+            state, loss = train_step_oneint(state, bx, by, dyn_params)
+        else:
+            state, loss = train_step_fullint(state, bx, by)
+        losses.append(loss)
+    return state, (torch.cat(losses) if losses else torch.zeros(0, device=state.flat.device))

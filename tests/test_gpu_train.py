@@ -104,3 +104,35 @@ def test_training_reduces_the_loss(gpu):
         losses.append(loss)
     l = torch.cat(losses).cpu().numpy()
     assert np.isfinite(l).all() and l[-1] < 0.6 * l[0]
+
+
+def test_train_epoch_over_device_table(gpu, tmp_path):
+    """.npz table -> prepare (mirror + flatten) -> model card -> device-resident epochs
+    (scripts/train_nmpc.py:455-486).  Every row is visited at most once per epoch, the remainder is
+    dropped, the loss decreases over epochs."""
+    from irbfn_amd import tables
+    rng = np.random.default_rng(5)
+    n = 3000
+    inputs = rng.uniform([0, 0, 0, 0, 0, -0.6, -3.0], [7, 3.6, 3.6, 3.2, 7, 0.4, 2.5], size=(n, 7)).round(2)
+    outputs = np.stack([np.sin(inputs[:, [1]]) * np.linspace(1, 2, 5), np.cos(inputs[:, [2]]) * np.linspace(0.2, 1, 5)], axis=-1)
+    path = str(tmp_path / "table.npz")
+    np.savez(path, inputs=inputs, outputs=outputs)
+    fx, fy = tables.prepare(path, tables.CARTESIAN, mirror_data=True)
+    assert fx.shape == (2 * n, 7) and fy.shape == (2 * n, 10)
+    card = tables.model_card(fx, fy, [1] * 7, 128, "gaussian")
+    net = WCRBFNet.from_config(card)
+    params = net.init(seed=1)
+    params["params"]["rbf_list"]["centers"] = rng.uniform(-4, 8, size=(1, 128, 7)).astype(np.float32)
+    table = tables.DeviceTable(fx, fy, seed=7)
+    batches = list(table.epoch(1024))
+    assert len(batches) == 5 and batches[0][0].shape == (1024, 7) and batches[0][1].shape == (1024, 10)
+    seen = torch.cat([b[0] for b in batches])
+    # rows of one epoch are distinct table rows (x rows are unique with overwhelming probability)
+    assert torch.unique(seen, dim=0).shape[0] == seen.shape[0]
+    state = train.TrainState.create(net, params, lr=5e-3, max_grad_norm=1.0)
+    means = []
+    for _ in range(8):
+        state, losses = train.train_epoch(state, table, 1024)
+        assert losses.shape == (5,)
+        means.append(float(losses.mean()))
+    assert np.isfinite(means).all() and means[-1] < 0.8 * means[0], means
