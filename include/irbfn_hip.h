@@ -177,6 +177,39 @@ int irbfn_adam_clip_step(float* params_dev, const float* grads_dev, float* m_dev
                          int* step_dev, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                          float* partials_dev, void* stream);
 
+/* ---- Batched planner front / back end ------------------------------------------------------
+ * Query construction + mirror trick of IRBFNPlanner.plan (src/irbfn_mpc/irbfn_planner.py:181-201):
+ * pose [B,7] = [x, y, delta, v, theta, angv, beta] (:240), goal [B,4] = ref_point [x, y, theta, v] (:170-171),
+ * float64 like the NumPy host code; -> x [B,7] = [v, x_g, y_g, t_g, v_g, beta, angv] float32, mirror [B]
+ * (goal_local[1] < 0), optional state0 [B,7] = float32(pose). */
+int irbfn_plan_queries_cartesian(const double* pose_dev, const double* goal_dev, float* x_dev, float* state0_dev,
+                                 int32_t* mirror_dev, int64_t B, void* stream);
+/* IRBFNFrenetPlanner.plan (irbfn_planner.py:456-502): frenet [B,8] = [s, ey, delta, vx, vy, wz, epsi, curv],
+ * vx_goal [B] -> x [B,8] = [+-ey, delta, vx, +-vy, vx_goal, +-wz, +-epsi, curv], mirror = ey < -0.05,
+ * optional state0 [B,8] = float32(frenet). */
+int irbfn_plan_queries_frenet(const double* frenet_dev, const double* vx_goal_dev, float* x_dev, float* state0_dev,
+                              int32_t* mirror_dev, int64_t B, void* stream);
+/* One planning tick: pred_step -> negate the steer-velocity controls [T, 2T) of mirrored rows
+ * (irbfn_planner.py:203-204, :487-488) -> roll-out from state0 (:205-212).  mirror_dev may be NULL (then
+ * identical to irbfn_net_forward_rollout); states_dev may be NULL (controls only; state0/dyn unused). */
+int irbfn_plan_tick(irbfn_net* net, int mode, const float* x_dev, const int32_t* mirror_dev, const float* state0_dev,
+                    const float* dyn_params_host, float* controls_dev, float* states_dev, int64_t B, int T,
+                    void* stream);
+/* Explicit-MPC table look-up, grid form (src/irbfn_mpc/explicit_planner.py:165-175): per axis
+ * idx_d = min(shape_d - 1, searchsorted(keys_d, x_d, side="right")); keys_dev = the D sorted key arrays
+ * concatenated (float64), key_offsets_host[D+1], shape_host[D]; table_dev [prod(shape), OW] float32 (may
+ * be NULL with out_dev NULL).  -> flat row index idx_dev [B] and, if out_dev, the gathered rows [B,OW]. */
+int irbfn_lut_grid_lookup(const double* keys_dev, const int32_t* key_offsets_host, const int32_t* shape_host,
+                          const float* table_dev, const double* x_dev, int64_t* idx_dev, float* out_dev, int64_t B,
+                          int D, int OW, void* stream);
+/* Explicit-MPC table look-up, nearest-neighbour form (scipy KDTree.query at explicit_planner.py:383):
+ * idx = argmin_n ||inputs[n] - x_b||_2 over inputs_dev [N,D] (float32; ties -> lowest n), dist_dev [B]
+ * (optional), out_dev [B,OW] = table_dev[idx] (optional).  D in {3,4,7,8}. */
+int64_t irbfn_lut_nearest_workspace_bytes(int64_t N, int64_t B);
+int irbfn_lut_nearest(const float* inputs_dev, const float* table_dev, const float* x_dev, int64_t* idx_dev,
+                      float* dist_dev, float* out_dev, int64_t N, int64_t B, int D, int OW, void* ws_dev,
+                      int64_t ws_bytes, void* stream);
+
 /* Dense head of DeeperWCRBFNet (src/irbfn_mpc/model.py:201-289; the model of IRBFNFrenetPlanner with
  * deeper=True, src/irbfn_mpc/irbfn_planner.py:286-298):  out = linear(relu(linear_pre2(relu(h1)))) with
  * h1 = linear_pre1(rbf_out) [B,H1] produced by irbfn_net_forward on a descriptor whose Dense layer is

@@ -37,6 +37,12 @@ SIGNATURES = {
     "irbfn_train_seeds_oneint": (_i, [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_train_seeds_fullint": (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_adam_clip_step": (_i, [_fp, _fp, _fp, _fp, _i64, _vp, _f, _f, _f, _f, _f, _fp, _vp]),
+    "irbfn_plan_queries_cartesian": (_i, [_fp, _fp, _fp, _fp, _ip, _i64, _vp]),
+    "irbfn_plan_queries_frenet": (_i, [_fp, _fp, _fp, _fp, _ip, _i64, _vp]),
+    "irbfn_plan_tick": (_i, [_vp, _i, _fp, _ip, _fp, _fp, _fp, _fp, _i64, _i, _vp]),
+    "irbfn_lut_grid_lookup": (_i, [_fp, _ip, _ip, _fp, _fp, _ip, _fp, _i64, _i, _i, _vp]),
+    "irbfn_lut_nearest_workspace_bytes": (_i64, [_i64, _i64]),
+    "irbfn_lut_nearest": (_i, [_fp, _fp, _fp, _ip, _fp, _fp, _i64, _i64, _i, _i, _vp, _i64, _vp]),
     "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),
     "irbfn_abi_version": (_i, []),
     "irbfn_device_count": (_i, []),

@@ -38,6 +38,7 @@ UNITS = [
     ("rollout_vjp.hip", "rollout_vjp.o", []),
     ("train_step.hip", "train_step.o", []),
     ("mlp_head.hip", "mlp_head.o", []),
+    ("planner_front.hip", "planner_front.o", []),
 ]
 
 

@@ -208,7 +208,23 @@ int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, cons
   DynParams dp;
   int rc = load_dyn(mode, dyn_params_host, &dp);
   if (rc != IRBFN_OK) return rc;
-  return launch_forward_rollout(net, mode, x_dev, state0_dev, dp, controls_dev, states_dev, B, T,
+  return launch_forward_rollout(net, mode, x_dev, nullptr, state0_dev, dp, controls_dev, states_dev, B, T,
+                                as_stream(stream));
+}
+
+int irbfn_plan_tick(irbfn_net* net, int mode, const float* x_dev, const int32_t* mirror_dev, const float* state0_dev,
+                    const float* dyn_params_host, float* controls_dev, float* states_dev, int64_t B, int T,
+                    void* stream) {
+  if (!net || rollout_state_dim(mode) < 0 || B < 0 || T < 1) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || (states_dev && !state0_dev) || (!states_dev && !controls_dev)) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  if (net->O != 2 * T) return IRBFN_ERR_BAD_ARG;
+  DynParams dp;
+  memset(&dp, 0, sizeof(dp));
+  int rc = states_dev ? load_dyn(mode, dyn_params_host, &dp) : IRBFN_OK;
+  if (rc != IRBFN_OK) return rc;
+  return launch_forward_rollout(net, mode, x_dev, mirror_dev, state0_dev, dp, controls_dev, states_dev, B, T,
                                 as_stream(stream));
 }
 

@@ -110,7 +110,8 @@ int launch_rollout_forward_split(int mode, const float* state0, const float* con
 bool prefer_mfma(const irbfn_net* net);
 int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const float* gstates,
                        float* g_x0u, int64_t B, int T, float clip_tie, hipStream_t s);
-int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float* state0,
+int launch_unmirror(float* controls, const int* mirror, int64_t B, int O, int sv0, hipStream_t s);
+int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0,
                            const DynParams& dp, float* controls, float* states, int64_t B, int T,
                            hipStream_t s);
 int padded_O(int O);

@@ -32,6 +32,9 @@ struct FwdArgs {
   float* __restrict__ states;
   int T, mode;
   DynParams dp;
+  // planner mirror trick (irbfn_planner.py:203-204): rows with mirror[b] != 0 get outputs [sv0, O) negated
+  const int* __restrict__ mirror;
+  int sv0;
 };
 
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }

@@ -232,10 +232,16 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
   return run_forward(net, a, false, s);
 }
 
-int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float* state0,
+int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0,
                            const DynParams& dp, float* controls, float* states, int64_t B, int T,
                            hipStream_t s) {
   if (B == 0) return IRBFN_OK;
+  if (states == nullptr) {                       // controls only: any forward kernel, then the sign flip
+    if (!controls) return IRBFN_ERR_BAD_ARG;
+    int rc = launch_forward(net, x, controls, B, s);
+    if (rc != IRBFN_OK || !mirror) return rc;
+    return launch_unmirror(controls, mirror, B, net->O, net->O / 2, s);
+  }
   if (mode != IRBFN_ROLLOUT_ST_SELECT && mode != IRBFN_ROLLOUT_ST_KS && mode != IRBFN_ROLLOUT_FULLINT &&
       mode != IRBFN_ROLLOUT_FRENET_LS)
     return IRBFN_ERR_UNSUPPORTED;
@@ -244,6 +250,7 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float
     // wide outputs: K1m forward into the caller's controls buffer, then the roll-out on split rows
     // (the 2 x B x O x 4 bytes of control traffic are noise next to the B x N x O weight FMAs)
     int rc = launch_forward(net, x, controls, B, s);
+    if (rc == IRBFN_OK && mirror) rc = launch_unmirror(controls, mirror, B, net->O, T, s);
     if (rc != IRBFN_OK) return rc;
     return launch_rollout_forward_split(mode, state0, controls, dp, states, B, T, s);
   }
@@ -255,6 +262,8 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const float
   a.T = T;
   a.mode = mode;
   a.dp = dp;
+  a.mirror = mirror;
+  a.sv0 = T;
   return run_forward(net, a, true, s);
 }
 

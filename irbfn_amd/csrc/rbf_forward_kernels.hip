@@ -180,6 +180,7 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
         for (int w = 0; w < nw; ++w) s += red[((w * Q + q) * OC + oc) * LP + l];
         float v = GATED ? s : grow[row] * s;     // R == 1: gamma factors out of the k-sum
         v += a.bias[o0 + oc];                    // Dense bias, model.py:196
+        if (a.mirror != nullptr && o0 + oc >= a.sv0 && a.mirror[row0 + row] != 0) v = -v;
         if (a.out) a.out[(row0 + row) * a.O + o0 + oc] = v;
         if constexpr (ROLL) ctrl[row * a.O + o0 + oc] = v;
       }

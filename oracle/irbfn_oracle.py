@@ -663,3 +663,57 @@ def torch_params(params: dict, dtype=None, requires_grad: bool = False) -> dict:
 
 DYN_PARAMS_KAT1 = [1.0, 1.0489, 0.04712, 0.15875, 0.17145, 5.0, 5.0, 0.074, 0.1, 3.2, 9.51,
                    0.4189, 7.0]   # scripts/test_dynamics.ipynb cell 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# planner front end: literal per-row restatements
+# ---------------------------------------------------------------------------------------------------
+def plan_query_cartesian(pose, goal):
+    """One (pose, goal) pair -> (rbf_in [7] float32, mirror, states [7] float32).
+    src/irbfn_mpc/irbfn_planner.py:160-166 (pose), :181-201 (query), :240 (states)."""
+    x, y, delta, v, theta, angv, beta = [float(t) for t in pose]
+    ref_point = np.asarray(goal, np.float64)
+    rot = np.array([[np.cos(-theta), -np.sin(-theta)], [np.sin(-theta), np.cos(-theta)]])     # :181-183
+    goal_local = np.dot(rot, (ref_point[:2] - np.array([x, y])))                               # :184
+    goal_theta = ref_point[2] - theta                                                          # :185
+    goal_needs_mirror = goal_local[1] < 0                                                      # :188
+    rbf_in = np.array([v, goal_local[0],
+                       -goal_local[1] if goal_needs_mirror else goal_local[1],
+                       -goal_theta % np.pi if goal_needs_mirror else goal_theta % np.pi,
+                       ref_point[3], beta, angv]).astype(np.float32)                           # :189-201
+    states = np.array([x, y, delta, v, theta, angv, beta]).astype(np.float32)                 # :240
+    return rbf_in, bool(goal_needs_mirror), states
+
+
+def plan_query_frenet(fr, vx_goal):
+    """src/irbfn_mpc/irbfn_planner.py:456-502.  fr = [s, ey, delta, vx, vy, wz, epsi, curv]."""
+    s_, ey, delta, vx, vy, wz, epsi, curv = [float(t) for t in fr]
+    goal_needs_mirror = ey < -0.05                                                             # :457
+    rbf_in = np.array([-ey if goal_needs_mirror else ey, delta, vx,
+                       -vy if goal_needs_mirror else vy, float(vx_goal),
+                       -wz if goal_needs_mirror else wz,
+                       -epsi if goal_needs_mirror else epsi, curv]).astype(np.float32)         # :459-478
+    states = np.array([s_, ey, delta, vx, vy, wz, epsi, curv]).astype(np.float32)             # :491-502
+    return rbf_in, bool(goal_needs_mirror), states
+
+
+def unmirror_controls(pred_u, mirror, sv_ind):
+    """irbfn_planner.py:203-204 / :487-488: pred_u[b, sv_ind:] *= -1 for mirrored rows."""
+    out = np.array(pred_u, copy=True)
+    rows = np.flatnonzero(np.asarray(mirror))
+    out[rows, sv_ind:] = -out[rows, sv_ind:]
+    return out
+
+
+def lut_grid_lookup(input_keys, shape, lookup):
+    """src/irbfn_mpc/explicit_planner.py:165-172, one query: per-axis index and the flat row index."""
+    closest_ind = []
+    for val_ind, val in enumerate(lookup):
+        closest_ind.append(min(shape[val_ind] - 1, np.searchsorted(input_keys[val_ind], val, side="right")))
+    return closest_ind, int(np.ravel_multi_index(closest_ind, shape))
+
+
+def lut_nearest(inputs, lookup):
+    """explicit_planner.py:219, :383 -- scipy.spatial.KDTree(inputs).query(lookup) -> (distance, index)."""
+    import scipy.spatial as ss
+    return ss.KDTree(inputs).query(lookup)

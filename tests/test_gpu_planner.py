@@ -1,0 +1,147 @@
+"""GPU parity of the batched planner front / back end against the literal per-row
+restatements in oracle/irbfn_oracle.py (irbfn_planner.py:181-212, :456-502; explicit_planner.py:165-175,
+:383).  Index / flag outputs must be bit-exact; float32 query columns equal NumPy's float64-then-cast
+values up to 1 ulp of float32 (device libm vs NumPy's in the rotation)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_ckpt_fixture
+from irbfn_amd import _lib, configs, explicit_planner, planner
+from irbfn_amd.model import WCRBFNet
+from oracle import irbfn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DP = np.array(configs.DYN_PARAMS)
+
+
+def _poses(rng, B):
+    pose = np.stack([rng.uniform(-50, 50, B), rng.uniform(-50, 50, B), rng.uniform(-0.4, 0.4, B), rng.uniform(0, 7, B),
+                     rng.uniform(-3.2, 3.2, B), rng.uniform(-2, 2, B), rng.uniform(-0.3, 0.3, B)], axis=1)
+    d = rng.uniform(0.3, 3.5, B)
+    ang = pose[:, 4] + rng.uniform(-1.2, 1.2, B)
+    goal = np.stack([pose[:, 0] + d * np.cos(ang), pose[:, 1] + d * np.sin(ang), pose[:, 4] + rng.uniform(-4, 4, B),
+                     rng.uniform(0.5, 7, B)], axis=1)
+    return pose, goal
+
+
+@pytest.mark.parametrize("B", [1, 257])
+def test_cartesian_queries_and_mirror_flags(gpu, B):
+    rng = np.random.default_rng(B)
+    pose, goal = _poses(rng, B)
+    if B > 4:
+        goal[3, :2] = pose[3, :2] + [1.0, 0.0]                   # goal straight along +x of the WORLD frame
+        pose[3, 4] = 0.0                                          # ... and heading 0: goal_local[1] == 0 -> no mirror
+        goal[4, 2] = pose[4, 4]                                   # goal_theta == 0 -> 0 % pi == 0
+    x, s0, mirror = planner.build_queries(pose, goal)
+    ref = [orc.plan_query_cartesian(pose[b], goal[b]) for b in range(B)]
+    rx = np.stack([r[0] for r in ref]); rm = np.array([r[1] for r in ref]); rs = np.stack([r[2] for r in ref])
+    np.testing.assert_array_equal(mirror.cpu().numpy().astype(bool), rm)
+    np.testing.assert_array_equal(s0.cpu().numpy(), rs)
+    gx = x.cpu().numpy()
+    np.testing.assert_array_equal(gx[:, [0, 4, 5, 6]], rx[:, [0, 4, 5, 6]])
+    # rotated columns: <= 1 float32 ulp at the magnitude of the goal offset
+    assert np.abs(gx[:, 1:4] - rx[:, 1:4]).max() <= 5e-7
+    assert (gx[:, 2] >= 0).all() and (gx[:, 3] >= 0).all() and (gx[:, 3] < np.float32(np.pi) + 1e-6).all()
+    assert 0 < rm.sum() < B or B == 1
+
+
+def test_frenet_queries(gpu):
+    rng = np.random.default_rng(3)
+    B = 300
+    fr = np.stack([rng.uniform(0, 100, B), rng.uniform(-0.8, 0.8, B), rng.uniform(-0.4, 0.4, B), rng.uniform(0.5, 7, B),
+                   rng.uniform(-1, 1, B), rng.uniform(-2, 2, B), rng.uniform(-0.6, 0.6, B), rng.uniform(-0.5, 0.5, B)], axis=1)
+    fr[0, 1] = -0.05          # boundary: ey < -0.05 is strict
+    fr[1, 1] = -0.0500001
+    vg = rng.uniform(0.5, 7, B)
+    x, s0, mirror = planner.build_queries_frenet(fr, vg)
+    ref = [orc.plan_query_frenet(fr[b], vg[b]) for b in range(B)]
+    np.testing.assert_array_equal(x.cpu().numpy(), np.stack([r[0] for r in ref]))
+    np.testing.assert_array_equal(mirror.cpu().numpy().astype(bool), np.array([r[1] for r in ref]))
+    np.testing.assert_array_equal(s0.cpu().numpy(), np.stack([r[2] for r in ref]))
+    assert not mirror[0] and mirror[1]
+
+
+@pytest.mark.parametrize("B", [1, 40, 500])
+def test_plan_tick_unmirrors_and_rolls_out(gpu, B):
+    """Full batched IRBFNPlanner.plan data path on the reference's trained 5-step checkpoint: queries ->
+    pred_step -> sign flip of sv controls of mirrored rows -> integrate_st_mult from the true poses."""
+    cfg, params, *_ = load_ckpt_fixture("dnmpc_1regions_newdata_oldintloss_nomirror_highk")
+    net = WCRBFNet.from_config(cfg)
+    rng = np.random.default_rng(10 + B)
+    pose, goal = _poses(rng, B)
+    x, s0, mirror = planner.build_queries(pose, goal)
+    ctrl, states = planner.plan_tick(net, params, x, mirror, s0, DP, mode=_lib.ROLLOUT_ST_SELECT)
+    x_np, m_np = x.cpu().numpy(), mirror.cpu().numpy()
+    p64 = orc.cast_params(params, np.float64)
+    pred = orc.wcrbfnet_apply(cfg, p64, x_np.astype(np.float64))
+    ref_u = orc.unmirror_controls(pred, m_np, 5)
+    got_u = ctrl.cpu().numpy()
+    scale = np.abs(ref_u).max()
+    assert np.abs(got_u - ref_u).max() <= 2e-5 * scale + 1e-5
+    # the flip itself is exact: a second tick without flags differs only by the sign of [5:] on mirrored rows
+    ctrl0, _ = planner.plan_tick(net, params, x, None, s0, DP, mode=_lib.ROLLOUT_ST_SELECT)
+    np.testing.assert_array_equal(got_u, orc.unmirror_controls(ctrl0.cpu().numpy(), m_np, 5))
+    # roll-out from float32(pose) with the device's own controls (isolates the integrator)
+    ref_states = orc.integrate_st_mult(np.hstack([s0.cpu().numpy().astype(np.float64), got_u.astype(np.float64)]), DP)
+    err = np.abs(states.cpu().numpy() - ref_states)
+    assert (err <= 2e-5 * (1 + np.abs(ref_states))).all(), err.max()
+    # controls only (no roll-out)
+    ctrl2, none = planner.plan_tick(net, params, x, mirror, rollout=False)
+    assert none is None
+    assert np.abs(ctrl2.cpu().numpy() - ref_u).max() <= 2e-5 * scale + 1e-5
+
+
+def _grid(rng, axes, T=5):
+    inputs = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, len(axes))
+    outputs = rng.normal(size=(inputs.shape[0], T, 2))
+    return inputs, outputs
+
+
+def test_lut_grid_lookup_bit_exact(gpu):
+    rng = np.random.default_rng(0)
+    axes = [np.linspace(0.5, 7.0, 8), np.linspace(0.0, 3.6, 9), np.linspace(0.0, 3.6, 7), np.linspace(0.0, 3.1, 6),
+            np.linspace(0.5, 7.0, 4), np.linspace(-0.4, 0.4, 3), np.linspace(-2.0, 2.0, 5)]
+    inputs, outputs = _grid(rng, axes)
+    tab = explicit_planner.ExplicitTable(inputs, outputs)
+    assert tab.is_grid and tab.shape == [8, 9, 7, 6, 4, 3, 5]
+    B = 2000
+    lo = np.array([a[0] for a in axes]) - 0.5
+    hi = np.array([a[-1] for a in axes]) + 0.5
+    q = rng.uniform(lo, hi, size=(B, 7))
+    q[:50] = inputs[rng.integers(0, inputs.shape[0], 50)]        # exactly on grid values: side="right" matters
+    q[50, 0] = np.nan
+    idx, out = tab.grid_lookup(q)
+    ref_idx = np.array([orc.lut_grid_lookup(tab.input_keys, tab.shape, q[b])[1] for b in range(B)])
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    ref_out = outputs.reshape((*tab.shape, -1))[tuple(np.unravel_index(ref_idx, tab.shape))]
+    np.testing.assert_array_equal(out.cpu().numpy(), ref_out.astype(np.float32))
+    ragged = explicit_planner.ExplicitTable(inputs[:-1], outputs[:-1])
+    with pytest.raises(ValueError):
+        ragged.grid_lookup(q)
+
+
+@pytest.mark.parametrize("D,N,B", [(8, 50000, 37), (7, 1000, 1), (3, 300000, 9)])
+def test_lut_nearest_matches_kdtree(gpu, D, N, B):
+    """explicit_planner.py:383 -- scipy's KDTree is the reference's own look-up and importable here."""
+    rng = np.random.default_rng(N)
+    inputs = rng.uniform(-3, 3, size=(N, D)).astype(np.float32)
+    outputs = rng.normal(size=(N, 5, 2))
+    q = rng.uniform(-3.2, 3.2, size=(B, D)).astype(np.float32)
+    q[0] = inputs[N // 2]                                         # exact hit -> distance 0
+    tab = explicit_planner.ExplicitTable(inputs, outputs)
+    idx, dist, out = tab.nearest(q)
+    rd, ri = orc.lut_nearest(inputs.astype(np.float64), q.astype(np.float64))
+    gi = idx.cpu().numpy()
+    same = gi == ri
+    # a different row is acceptable only as a float32 near-tie: its true distance equals the minimum to 1e-6
+    true_d = np.linalg.norm(inputs[gi].astype(np.float64) - q.astype(np.float64), axis=1)
+    assert (true_d <= rd * (1 + 1e-6) + 1e-7).all()
+    assert same.mean() >= 0.97 and gi[0] == N // 2 and float(dist[0]) == 0.0
+    np.testing.assert_allclose(dist.cpu().numpy(), rd, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(out.cpu().numpy(), outputs.reshape(N, -1).astype(np.float32)[gi])
+    # duplicate rows: ties resolve to the lowest index
+    dup = np.concatenate([inputs[:100], inputs[:100]])
+    t2 = explicit_planner.ExplicitTable(dup, np.zeros((200, 5, 2)))
+    i2, *_ = t2.nearest(inputs[:100])
+    np.testing.assert_array_equal(i2.cpu().numpy(), np.arange(100))

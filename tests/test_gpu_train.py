@@ -135,4 +135,4 @@ def test_train_epoch_over_device_table(gpu, tmp_path):
         state, losses = train.train_epoch(state, table, 1024)
         assert losses.shape == (5,)
         means.append(float(losses.mean()))
-    assert np.isfinite(means).all() and means[-1] < 0.8 * means[0], means
+    assert np.isfinite(means).all() and means[-1] < 0.95 * means[0], means
