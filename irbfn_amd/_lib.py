@@ -6,7 +6,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirbfn_hip.so")
+LIB_PATH = os.environ.get("IRBFN_LIB") or os.path.join(_HERE, "libirbfn_hip.so")   # IRBFN_LIB: A/B builds (tools/build_variant.sh)
 
 IRBFN_OK = 0
 STATUS_NAMES = {0: "IRBFN_OK", -1: "IRBFN_ERR_BAD_ARG", -2: "IRBFN_ERR_UNSUPPORTED", -3: "IRBFN_ERR_HIP",

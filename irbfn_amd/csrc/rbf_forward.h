@@ -71,6 +71,50 @@ __device__ __forceinline__ float basis_from_r2(float r2, float sc, int basis) {
   }
 }
 
+// ---- batched transcendentals ----------------------------------------------------------------------------
+// On gfx950 ONE v_exp_f32 / v_rcp_f32 / v_rsq_f32 inside a stream of plain VALU costs ~33 cycles of SIMD
+// time, the same instruction issued back to back costs 8 (tools/ubench_trans.hip,
+// profiles/r01_ubench_trans_hazard.txt): the basis of G centres is therefore evaluated as one block.
+// basis_arg: everything in front of the transcendental; trans_block: NT of them adjacent (inline asm: the
+// compiler would re-interleave them with the distance arithmetic); s_nop: trans -> VALU forwarding hazard.
+template <int BC>
+__device__ __forceinline__ float basis_arg(float r2, float sc) {
+  if constexpr (BC == BC_GAUSS) return r2 * sc;            // phi = 2^(r2*sc)
+  else return __builtin_fmaf(r2, sc, 1.0f);                // IQ: 1/(1+d2), IMQ: (1+d2)^-1/2
+}
+
+// wait states around the block: a plain VALU instruction right behind (or in front of) a transcendental
+// triggers a hardware interlock that costs 10-15 cycles; explicit wait states are cheaper
+// (tools/ubench_k1body.hip: 94 -> 82 cycles per centre with s_nop 7)
+#ifndef IRBFN_TRANS_PRE
+#define IRBFN_TRANS_PRE ""
+#endif
+#ifndef IRBFN_TRANS_POST
+#define IRBFN_TRANS_POST "s_nop 7"
+#endif
+#define IRBFN_TRANS4(OP, A, B, C, E) OP " %" #A ", %" #A "\n " OP " %" #B ", %" #B "\n " OP " %" #C ", %" #C "\n " OP " %" #E ", %" #E "\n "
+template <int BC, int NT>
+__device__ __forceinline__ void trans_block(float (&v)[NT]) {
+  static_assert(NT == 2 || NT == 4 || NT == 8 || NT == 16, "trans_block: 2, 4, 8 or 16 values");
+#define IRBFN_TRANS_EMIT(OP)                                                                                   \
+  if constexpr (NT == 2)                                                                                       \
+    asm volatile(OP " %0, %0\n " OP " %1, %1\n s_nop 0" : "+v"(v[0]), "+v"(v[1]));                             \
+  else if constexpr (NT == 4)                                                                                  \
+    asm volatile(IRBFN_TRANS_PRE IRBFN_TRANS4(OP, 0, 1, 2, 3) IRBFN_TRANS_POST : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));      \
+  else if constexpr (NT == 8)                                                                                  \
+    asm volatile(IRBFN_TRANS_PRE IRBFN_TRANS4(OP, 0, 1, 2, 3) IRBFN_TRANS4(OP, 4, 5, 6, 7) IRBFN_TRANS_POST                            \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])); \
+  else                                                                                                         \
+    asm volatile(IRBFN_TRANS_PRE IRBFN_TRANS4(OP, 0, 1, 2, 3) IRBFN_TRANS4(OP, 4, 5, 6, 7) IRBFN_TRANS4(OP, 8, 9, 10, 11) \
+                 IRBFN_TRANS4(OP, 12, 13, 14, 15) IRBFN_TRANS_POST                                                     \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), \
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+  if constexpr (BC == BC_GAUSS) { IRBFN_TRANS_EMIT("v_exp_f32_e32") }
+  else if constexpr (BC == BC_IQ) { IRBFN_TRANS_EMIT("v_rcp_f32_e32") }
+  else { IRBFN_TRANS_EMIT("v_rsq_f32_e32") }
+#undef IRBFN_TRANS_EMIT
+}
+
 // one factor of the smooth indicator: ((tanh(delta*(x-lo))+1)/2) * ((tanh(delta*(hi-x))+1)/2), model.py:83-85
 __device__ __forceinline__ float gate_factor(float xv, float lo, float hi, float delta) {
   return ((tanhf(delta * (xv - lo)) + 1.0f) * 0.5f) * ((tanhf(delta * (hi - xv)) + 1.0f) * 0.5f);

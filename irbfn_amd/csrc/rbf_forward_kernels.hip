@@ -16,8 +16,10 @@ struct RecLayout {
 
 // (query, centre) pair: distance, basis, weight-row FMA.  `rp` is wave-uniform -> SGPR operands.
 template <int D, int OP, int Q, int BC, bool GATED>
-__device__ __forceinline__ void pair_body(const float* __restrict__ rp, const float (&xq)[Q][D],
+__device__ __forceinline__ void pair_body(const float* __restrict__ rp_, const float (&xq)[Q][D],
                                           float (&acc)[Q][OP], const float (&g)[Q], int basis) {
+  typedef const float __attribute__((address_space(4)))* crec_t;
+  const crec_t rp = (crec_t)(uintptr_t)rp_;    // scalar (s_load) path, see group_body
   float r2[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) r2[q] = 0.0f;
@@ -42,6 +44,51 @@ __device__ __forceinline__ void pair_body(const float* __restrict__ rp, const fl
     const float w = rp[D + 1 + o];
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q][o] = __builtin_fmaf(phi[q], w, acc[q][o]);   // model.py:196
+  }
+}
+
+// G centres at once: G distances, then the G*Q transcendentals as ONE block (rbf_forward.h: an isolated
+// transcendental costs ~4x a batched one), then the G weight rows.  Fast bases only.
+#ifndef IRBFN_FWD_G
+#define IRBFN_FWD_G 4
+#endif
+template <int D, int OP, int Q, int BC, bool GATED, int G>
+__device__ __forceinline__ void group_body(const float* __restrict__ rp, int S, const float (&xq)[Q][D],
+                                           float (&acc)[Q][OP], const float (&g)[Q]) {
+  // constant address space: keeps the record reads on the scalar path (s_load); with a volatile asm in the
+  // loop hipcc can no longer prove the buffer unclobbered and would fall back to per-lane global_load
+  typedef const float __attribute__((address_space(4)))* crec_t;
+  float t[G * Q];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const crec_t r = (crec_t)(uintptr_t)(rp + k * S);
+    float r2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) r2[q] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float c = r[j];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float d = xq[q][j] - c;
+        r2[q] = __builtin_fmaf(d, d, r2[q]);
+      }
+    }
+    const float sc = r[D];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) t[k * Q + q] = basis_arg<BC>(r2[q], sc);
+  }
+  trans_block<BC, G * Q>(t);
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const crec_t r = (crec_t)(uintptr_t)(rp + k * S);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float phi = t[k * Q + q];
+      if constexpr (GATED) phi *= g[q];
+#pragma unroll
+      for (int o = 0; o < OP; ++o) acc[q][o] = __builtin_fmaf(phi, r[D + 1 + o], acc[q][o]);
+    }
   }
 }
 
@@ -120,8 +167,17 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
   const int n0 = wave * per;
   const int n1 = (n0 + per) < a.N ? (n0 + per) : a.N;
   if constexpr (!GATED) {
+    int n = n0;
+    constexpr int G = IRBFN_FWD_G;
+    if constexpr (BC != BC_GENERIC && G > 1 && (G * Q <= 16)) {
+#ifdef IRBFN_DBG_RECMASK      // diagnosis only: every wave re-reads the same few records (scalar-cache hits)
+      for (; n + G <= n1; n += G) group_body<D, OP, Q, BC, false, G>(a.rec + (size_t)(n & IRBFN_DBG_RECMASK) * S, S, xq, acc, gam);
+#else
+      for (; n + G <= n1; n += G) group_body<D, OP, Q, BC, false, G>(a.rec + (size_t)n * S, S, xq, acc, gam);
+#endif
+    }
 #pragma unroll 2
-    for (int n = n0; n < n1; ++n)
+    for (; n < n1; ++n)
       pair_body<D, OP, Q, BC, false>(a.rec + (size_t)n * S, xq, acc, gam, a.basis);
   } else {
     int n = n0;
@@ -145,6 +201,10 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
       if (__ballot(any) == 0ull) {               // no query of this wave is inside region r
         n = nend;
         continue;
+      }
+      constexpr int G = IRBFN_FWD_G;
+      if constexpr (BC != BC_GENERIC && G > 1 && (G * Q <= 16)) {
+        for (; n + G <= nend; n += G) group_body<D, OP, Q, BC, true, G>(a.rec + (size_t)n * S, S, xq, acc, gam);
       }
       for (; n < nend; ++n)
         pair_body<D, OP, Q, BC, true>(a.rec + (size_t)n * S, xq, acc, gam, a.basis);
