@@ -129,13 +129,25 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
     if constexpr (GATED) gam = gmp[(long)i * a.R];
     else gam = qp[D];
     const float gphi = gam * phi;
-    float hbar = 0.0f;
+    // hbar as two interleaved partial sums: hipcc's SLP turns the pair into v_pk_fma_f32 with an SGPR-pair
+    // operand (4.7 cycles per two FMAs; a v_fmac with one SGPR and two VGPR reads costs 4.2 for one).
+    // Measured and rejected: 4 queries per step with one block of 4 transcendentals (as in the forward
+    // kernel): 90 VGPRs, 411 vs 404 us -- this kernel is bound by its ~38 VALU instructions per pair.
+    float hb0 = 0.0f, hb1 = 0.0f;
 #pragma unroll
-    for (int o = 0; o < OP; ++o) {
-      const float go = qp[D + 1 + o];
-      hbar = __builtin_fmaf(go, w[o], hbar);
-      gw[o] = __builtin_fmaf(gphi, go, gw[o]);
+    for (int o = 0; o + 1 < OP; o += 2) {
+      const float g0 = qp[D + 1 + o], g1 = qp[D + 2 + o];
+      hb0 = __builtin_fmaf(g0, w[o], hb0);
+      hb1 = __builtin_fmaf(g1, w[o + 1], hb1);
+      gw[o] = __builtin_fmaf(gphi, g0, gw[o]);
+      gw[o + 1] = __builtin_fmaf(gphi, g1, gw[o + 1]);
     }
+    if constexpr (OP & 1) {
+      const float g0 = qp[D + OP];
+      hb0 = __builtin_fmaf(g0, w[OP - 1], hb0);
+      gw[OP - 1] = __builtin_fmaf(gphi, g0, gw[OP - 1]);
+    }
+    const float hbar = hb0 + hb1;
     const float t = hbar * gam * dphi_dd2<BC>(phi, a.gscale, a.basis);
     gls = __builtin_fmaf(t, -2.0f * d2, gls);
     const float coef = -2.0f * t * s2;
