@@ -32,6 +32,7 @@ UNITS = [
     ("rbf_forward_kernels.hip", "rbf_fwd_d7.o", ["-DIRBFN_INST_D=7"] + _SLP),
     ("rbf_forward_kernels.hip", "rbf_fwd_d8.o", ["-DIRBFN_INST_D=8"] + _SLP),
     ("rbf_forward_mfma.hip", "rbf_fwd_mfma.o", []),
+    ("rbf_forward_f16.hip", "rbf_fwd_f16.o", []),
     ("rbf_forward_small.hip", "rbf_fwd_small.o", []),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rollout.hip", "rollout.o", []),

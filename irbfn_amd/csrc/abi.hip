@@ -79,6 +79,10 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   alloc((void**)&net->sig2, (size_t)net->N * sizeof(float));
   net->Npad = (net->N + 15) & ~15;
   if (mfma_eligible(net)) alloc((void**)&net->recm, (size_t)net->Npad * mfma_record_floats(D, O) * sizeof(float));
+  if (f16_eligible(net)) {
+    alloc((void**)&net->f16_img, f16_image_bytes(net));
+    alloc((void**)&net->f16_oscale, 16 * sizeof(float));
+  }
   alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
   alloc((void**)&net->small_ticket, small_ticket_count() * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMemset(net->small_ticket, 0, small_ticket_count() * sizeof(unsigned int));
@@ -106,7 +110,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
 
 int irbfn_net_destroy(irbfn_net* net) {
   if (!net) return IRBFN_OK;
-  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete net;
@@ -118,6 +122,7 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
   if (!net || !centers_dev || !log_sigs_dev || !kernel_dev || !bias_dev) return IRBFN_ERR_BAD_ARG;
   int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->recm) rc = launch_pack_mfma(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
+  if (rc == IRBFN_OK && net->f16_img) rc = launch_pack_f16(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
 }

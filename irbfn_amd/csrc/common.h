@@ -68,6 +68,8 @@ struct irbfn_net {
   float* sig2;  // [N]      exp(-2 log_sig) (device) -- VJP
   float* recm;  // [Npad][CW + 16*NT] records of the MFMA forward (K1m); NULL if not eligible
   int Npad;     // N rounded up to a multiple of 16 (MFMA chunk)
+  unsigned char* f16_img;   // chunk images of the f16-split matrix-core forward (K1h); NULL if not eligible
+  float* f16_oscale;        // [16] per-output power-of-two scale of the K1h weight split
   float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
   unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs
@@ -95,6 +97,10 @@ size_t mfma_record_floats(int D, int O);
 int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
                      hipStream_t s);
 int launch_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, int QJ, int nw, hipStream_t s);
+bool f16_eligible(const irbfn_net* net);
+size_t f16_image_bytes(const irbfn_net* net);
+int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
+int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s);
 size_t small_workspace_floats(int OP);
 int small_ticket_count();
 bool small_eligible(const irbfn_net* net, int64_t B);

@@ -107,6 +107,9 @@ int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStre
 // ------------------------------------------------------------------------------------------------
 // K1 dispatcher: picks queries-per-lane Q and waves-per-workgroup NW, sizes LDS, launches.
 // ------------------------------------------------------------------------------------------------
+#ifndef IRBFN_F16_DEFAULT
+#define IRBFN_F16_DEFAULT 0        // K1h opt-in until it is measured faster than K1 on every compiled shape
+#endif
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -219,6 +222,29 @@ static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t 
   return launch_forward_mfma(net, x, out, B, QJ, nw, s);
 }
 
+// K1h (Phi x W on the f16 matrix cores at float32 accuracy, rbf_forward_f16.hip): narrow outputs, one region.
+// IRBFN_FWD_F16 = 0 / 1 forces K1 / K1h; IRBFN_FWD_F16_TERMS = 1 selects the reduced-precision single-product
+// variant (reporting only).  Geometry: S centre slices x QG query groups of 32 per 8-wave block, S chosen so
+// that the launch has >= 8192 waves (8 per SIMD).
+static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
+  if (!net->f16_img) return IRBFN_ERR_UNSUPPORTED;
+  const int e = env_int("IRBFN_FWD_F16", IRBFN_F16_DEFAULT);
+  if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 2048)) return IRBFN_ERR_UNSUPPORTED;
+  const long groups = (B + 31) / 32;
+  long want = (8192 + groups - 1) / groups;
+  int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
+  S = pow2_floor(S);
+  if (S < want && S < 8) S *= 2;
+  const int nchunks = (net->N + 31) / 32;
+  while (S > 1 && nchunks / S < 2) S /= 2;
+  S = env_int("IRBFN_FWD_F16_S", S);
+  if (S < 1 || S > 8 || S > nchunks) S = 1;
+  int QG = env_int("IRBFN_FWD_F16_QG", 8 / S);
+  if (QG < 1 || S * QG > 8) QG = 1;
+  const int terms = env_int("IRBFN_FWD_F16_TERMS", 3);
+  return launch_forward_f16(net, x, out, B, S, QG, terms == 1 ? 1 : 3, s);
+}
+
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (B == 0) return IRBFN_OK;
   // K1s: small batches (planner ticks) -> centre-lane latency kernel; IRBFN_FWD_SMALL=0 forces K1
@@ -227,6 +253,7 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   }
   if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
+  if (try_forward_f16(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
   FwdArgs a;
   fill_args(net, a, x, out, B);
   return run_forward(net, a, false, s);

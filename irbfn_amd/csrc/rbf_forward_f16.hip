@@ -1,0 +1,358 @@
+// K1h: fused RBF forward for NARROW outputs (O <= 16) with the Phi x W reduction on the f16 matrix cores
+// at float32 accuracy.  Same mathematics as K1 (src/irbfn_mpc/model.py:169-198; RBF stage
+// flax_rbf.py:258-285): gamma * sum_k phi_k(x) W[k,:] + bias, single region (R == 1).
+//
+// Why: K1 sits at the VALU issue limit of its instruction mix (26 VALU instructions per (query,
+// centre) pair, 10 of them the weight-row FMAs).  An MFMA inside a VALU stream costs its plain 14-20 cycles
+// (no co-execution on gfx950) but does 8192 FMAs, so moving Phi x W to v_mfma_f32_16x16x32_f16 removes
+// those 10 instructions for 3 (the split below) plus ~6 cycles of MFMA per 64 pairs.
+//
+// Accuracy: f16 has 11 significant bits, so both operands are split into an (hi, lo) pair:
+//     phi' = 2^14 * phi           = ph + pl   (ph = phi' with the low 13 mantissa bits cleared: exact in f16;
+//                                              pl = f16_rtz(phi' - ph): 21-22 significant bits in total)
+//     W'   = W / s_o  (|W'| <= 1) = wh + wl   (round-to-nearest f16 pair: 22 bits; s_o = power of two >= max_k |W[k,o]|)
+//     phi' W' ~= ph*wh + pl*wh + ph*wl          (the f16 x f16 products are exact in f32; pl*wl < 2^-22 is dropped)
+// accumulated in f32 by the MFMA.  2^14 keeps phi' out of the f16 subnormals down to phi = 2^-28; it is
+// folded into the argument of the transcendental (free).  Measured on cfg-2 (tools/proto_f16split.hip):
+// max |err| / sum_k |phi_k W_k| = 6e-8 ... 1.7e-7 -- the f32 FMA chain of K1 measures 3e-6.
+// TERMS = 1 keeps only ph*wh (plain f16 operands, ~1e-4): the reduced-precision variant BASELINE config 5
+// asks to report; never the default.
+//
+// Layout (v_mfma_f32_16x16x32_f16: A[row l&15][k = 8(l>>4)+j], B[k][col l&15], D[row 4(l>>4)+reg][col l&15]):
+// rows = 16 queries, k = 32 centres of a chunk, cols = outputs.  A lane owns query (l & 15) of each of its
+// wave's two tiles and the 8 centres 8g..8g+7 (g = l >> 4) of every chunk: centre records are broadcast
+// reads from a wave-private LDS ring (double buffered, no block barriers in the loop), the W operands come
+// straight from HBM/L2 (one coalesced 16-byte load per lane and part).  The transcendentals of a step (16
+// per lane) are issued as ONE block (rbf_forward.h).  The MFMAs of step c are issued between the distance
+// computations of step c+1.  Centres are sliced across the S waves of a query group; the slices are
+// summed in fixed order through LDS (deterministic).
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rbf_forward.h"
+
+namespace irbfn {
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kF16Chunk = 32;                    // centres per chunk = MFMA K
+constexpr int kF16WBytes = 4 * 16 * 8 * 2;       // one W part of a chunk: [g][n][8] halfs = 1 KiB
+constexpr int f16_rf(int DC) { return DC <= 3 ? 4 : (DC <= 7 ? 8 : 12); }    // floats per centre record
+constexpr int f16_chunk_bytes(int DC) { return kF16Chunk * f16_rf(DC) * 4 + 2 * kF16WBytes; }
+
+struct F16Args {
+  const float* __restrict__ x;            // [B][Dreal]
+  const unsigned char* __restrict__ img;  // [nchunks][chunk image]
+  const float* __restrict__ oscale;       // [16] s_o
+  const float* __restrict__ bias;         // [OP]
+  float* __restrict__ out;                // [B][O]
+  GateTables gate;
+  long B;
+  int Dreal, O, nchunks, S, QG;
+};
+
+// ---- pack ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f16_colscale_kernel(const float* __restrict__ kernel, float* __restrict__ oscale,
+                                                           int K, int O) {
+  __shared__ float red[256];
+  const int o = blockIdx.x;
+  float m = 0.0f;
+  if (o < O)
+    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(kernel[(size_t)k * O + o]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float s = 1.0f;
+    const float mx = red[0];
+    if (mx > 0.0f && mx < 3.0e38f) {             // zero column / Inf / NaN: unscaled
+      int e;
+      (void)frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)  ->  2^e >= mx
+      s = ldexpf(1.0f, e);
+    }
+    oscale[o] = s;
+  }
+}
+
+// one thread per (chunk, centre-in-chunk): record + this centre's 16 weights of both parts
+__global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
+                                                       const float* __restrict__ kernel, const float* __restrict__ oscale,
+                                                       unsigned char* __restrict__ img, int N, int K, int D, int RF,
+                                                       int O, int bclass, float gscale, int nchunks) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nchunks * kF16Chunk) return;
+  const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
+  const int n = idx;                                         // centre index (R == 1: n == k)
+  const size_t cb = (size_t)kF16Chunk * RF * 4 + 2 * kF16WBytes;
+  unsigned char* p = img + (size_t)c * cb;
+  float* rec = reinterpret_cast<float*>(p) + kk * RF;
+  __half* wh = reinterpret_cast<__half*>(p + (size_t)kF16Chunk * RF * 4);
+  __half* wl = wh + kF16WBytes / 2;
+  const bool real = n < N;
+  for (int j = 0; j < RF - 1; ++j) rec[j] = (real && j < D) ? centers[(size_t)n * D + j] : 0.0f;
+  float sc = 0.0f;                                           // padding centre: phi' = 2^14 exactly, W' = 0
+  if (real) {
+    const float s2 = expf(-2.0f * log_sigs[n]);              // 1/sigma^2 (flax_rbf.py:280)
+    if (bclass == BC_GAUSS) sc = -gscale * 1.4426950408889634f * s2;   // phi' = 2^(r2*sc + 14)
+    else if (bclass == BC_IQ) sc = s2 * 6.103515625e-05f;              // phi' = 1 / (2^-14 + 2^-14 d2)
+    else sc = s2 * 3.725290298461914e-09f;                             // phi' = rsqrt(2^-28 + 2^-28 d2)
+  }
+  rec[RF - 1] = sc;
+  const int g = kk >> 3, j = kk & 7;
+  for (int o = 0; o < 16; ++o) {
+    float w = 0.0f;
+    if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
+    const __half h = __float2half_rn(w);
+    const __half l = __float2half_rn(w - __half2float(h));
+    wh[(g * 16 + o) * 8 + j] = h;
+    wl[(g * 16 + o) * 8 + j] = l;
+  }
+}
+
+// ---- kernel ----------------------------------------------------------------------------------------------
+template <int BC>
+__device__ __forceinline__ float f16_arg(float r2, float sc) {
+  if constexpr (BC == BC_GAUSS) return __builtin_fmaf(r2, sc, 14.0f);
+  else if constexpr (BC == BC_IQ) return __builtin_fmaf(r2, sc, 6.103515625e-05f);
+  else return __builtin_fmaf(r2, sc, 3.725290298461914e-09f);
+}
+
+template <int DC, int BC, int TERMS>
+__global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RF = f16_rf(DC);
+  constexpr int RECB = kF16Chunk * RF * 4;                   // record bytes per chunk
+  constexpr int CB = f16_chunk_bytes(DC);
+  constexpr int NV = RECB / 16;                              // 16-byte pieces of a record block (32 / 64 / 96)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S;
+  const int slice = wave % S, qg = wave / S;
+  const int g = lane >> 4, n = lane & 15;
+  const long q0 = ((long)blockIdx.x * a.QG + qg) * 32;       // this wave's 32 queries (two 16-row tiles)
+  float xq[2][DC];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long q = q0 + t * 16 + n;
+    q = q < a.B ? q : a.B - 1;
+    q = q < 0 ? 0 : q;
+#pragma unroll
+    for (int i = 0; i < DC; ++i) xq[t][i] = i < a.Dreal ? a.x[q * a.Dreal + i] : 0.0f;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < DC; ++i) asm volatile("" : "+v"(xq[t][i]));   // loads complete before the loop
+  unsigned char* mylds = lds + wave * (2 * RECB);
+  const int c0 = (int)((long)a.nchunks * slice / S), c1 = (int)((long)a.nchunks * (slice + 1) / S);
+  auto wave_sync = [&]() {                                   // wave-private ring: in-order LDS queue suffices
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto fetch_rec = [&](const unsigned char* gp, u4_t (&pre)[(NV + 63) / 64]) {
+#pragma unroll
+    for (int v = 0; v < (NV + 63) / 64; ++v)
+      if (v * 64 + lane < NV) pre[v] = reinterpret_cast<const u4_t*>(gp)[v * 64 + lane];
+  };
+  auto store_rec = [&](unsigned char* dst, const u4_t (&pre)[(NV + 63) / 64]) {
+#pragma unroll
+    for (int v = 0; v < (NV + 63) / 64; ++v)
+      if (v * 64 + lane < NV) reinterpret_cast<u4_t*>(dst)[v * 64 + lane] = pre[v];
+  };
+
+  f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  h8_t ah[2], al[2], bh, bl;                                 // operands of the PREVIOUS step (deferred MFMAs)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ah[0][j] = 0; ah[1][j] = 0; al[0][j] = 0; al[1][j] = 0; bh[j] = 0; bl[j] = 0; }
+  u4_t pre[(NV + 63) / 64];
+  if (c0 < c1) {
+    fetch_rec(a.img + (size_t)c0 * CB, pre);
+    store_rec(mylds, pre);
+  }
+  wave_sync();
+  for (int c = c0; c < c1; ++c) {
+    const unsigned char* cur = mylds + ((c - c0) & 1) * RECB;
+    unsigned char* nxt = mylds + ((c - c0 + 1) & 1) * RECB;
+    const unsigned char* gp = a.img + (size_t)c * CB;
+    const bool has_next = c + 1 < c1;
+    if (has_next) fetch_rec(gp + CB, pre);
+    const h8_t nbh = *reinterpret_cast<const h8_t*>(gp + RECB + lane * 16);
+    h8_t nbl = nbh;
+    if constexpr (TERMS >= 3) nbl = *reinterpret_cast<const h8_t*>(gp + RECB + kF16WBytes + lane * 16);
+    float t16[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* rp = reinterpret_cast<const float*>(cur) + (8 * g + j) * RF;
+      float r[RF];
+#pragma unroll
+      for (int v = 0; v < RF / 4; ++v) {
+        const f4_t rr = *reinterpret_cast<const f4_t*>(rp + 4 * v);
+        r[4 * v] = rr.x; r[4 * v + 1] = rr.y; r[4 * v + 2] = rr.z; r[4 * v + 3] = rr.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float r2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DC; ++i) {
+          const float d = xq[t][i] - r[i];                   // flax_rbf.py:280  (x - centers)
+          r2 = __builtin_fmaf(d, d, r2);
+        }
+        t16[t * 8 + j] = f16_arg<BC>(r2, r[RF - 1]);
+      }
+      // one deferred MFMA per centre: (tile, term) = (j & 1, j >> 1); terms: ph*wh, pl*wh, ph*wl
+      const int t = j & 1, m = j >> 1;
+      if (m < TERMS) {
+        const h8_t av = (m == 1) ? al[t] : ah[t];
+        const h8_t bv = (m == 2) ? bl : bh;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    trans_block<BC, 16>(t16);                                // phi' = 2^14 * phi for the step's 16 pairs
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float p0 = t16[t * 8 + 2 * jj], p1 = t16[t * 8 + 2 * jj + 1];
+        if constexpr (TERMS >= 2) {
+          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
+          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
+          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+          const h2_t ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
+          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
+          al[t][2 * jj] = (_Float16)ll[0]; al[t][2 * jj + 1] = (_Float16)ll[1];
+        } else {
+          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
+        }
+      }
+    bh = nbh; bl = nbl;
+    if (has_next) store_rec(nxt, pre);
+    wave_sync();
+  }
+  // drain the deferred MFMAs of the last step
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t], 0, 0, 0);
+    if constexpr (TERMS >= 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t], 0, 0, 0);
+    if constexpr (TERMS >= 3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t], 0, 0, 0);
+  }
+
+  // ---- smooth region gate of the single region (model.py:42-95), one value per query
+  const GateTables gt = a.gate;
+  float gam[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;                // model.py:70
+#pragma unroll
+    for (int d = 0; d < DC; ++d)
+      if (d < gt.nsplit && gt.n_ranges > 0) {
+        const int e = d * gt.max_ranges + gt.dim_ranges[d];
+        gv *= gate_factor(xq[t][d], gt.lo[e], gt.hi[e], gt.delta[d]);
+      }
+    gam[t] = gv;
+  }
+  // ---- sum the S centre slices in fixed order, scale, bias, store
+  __syncthreads();                                           // every wave is done with its ring
+  float* red = reinterpret_cast<float*>(lds);                // [QG][S][2][4][64]
+  float* gl = red + (size_t)a.QG * S * 2 * 4 * 64;           // [QG][32]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(((qg * S + slice) * 2 + t) * 4 + r) * 64 + lane] = acc[t][r];
+  if (slice == 0 && g == 0) { gl[qg * 32 + n] = gam[0]; gl[qg * 32 + 16 + n] = gam[1]; }
+  __syncthreads();
+  if (slice == 0 && n < a.O) {
+    const float sc = a.oscale[n] * 6.103515625e-05f;         // s_o * 2^-14
+    const float bi = a.bias[n];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.0f;
+        for (int s2 = 0; s2 < S; ++s2) v += red[(((qg * S + s2) * 2 + t) * 4 + r) * 64 + lane];
+        const int row = t * 16 + 4 * g + r;                  // D layout: row = 4 (lane >> 4) + reg
+        const long q = q0 + row;
+        if (q < a.B) a.out[q * a.O + n] = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);   // model.py:193-196
+      }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+bool f16_eligible(const irbfn_net* net) {
+  return net->R == 1 && net->bclass != BC_GENERIC && net->O <= 16 && (net->DC == 3 || net->DC == 4 || net->DC == 7 || net->DC == 8);
+}
+
+size_t f16_image_bytes(const irbfn_net* net) {
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  return (size_t)nchunks * f16_chunk_bytes(net->DC);
+}
+
+int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  hipLaunchKernelGGL(f16_colscale_kernel, dim3(16), dim3(256), 0, s, kernel, net->f16_oscale, net->K, net->O);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  const int total = nchunks * kF16Chunk;
+  hipLaunchKernelGGL(f16_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, centers, log_sigs, kernel,
+                     net->f16_oscale, net->f16_img, net->N, net->K, net->D, f16_rf(net->DC), net->O, net->bclass,
+                     gauss_scale(net->basis), nchunks);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int DC, int TERMS>
+static int launch_f16_bc(const F16Args& a, int bc, int grid, int block, size_t lds, hipStream_t s) {
+  switch (bc) {
+    case BC_GAUSS: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_GAUSS, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
+    case BC_IQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IQ, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
+    case BC_IMQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IMQ, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int DC>
+static int launch_f16_dc(const F16Args& a, int terms, int bc, int grid, int block, size_t lds, hipStream_t s) {
+  return terms == 1 ? launch_f16_bc<DC, 1>(a, bc, grid, block, lds, s) : launch_f16_bc<DC, 3>(a, bc, grid, block, lds, s);
+}
+
+// S = centre slices per query group, QG = query groups (of 32) per block; S * QG <= 8 waves
+int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s) {
+  if (!net->f16_img || !f16_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  if (S < 1 || QG < 1 || S * QG > 8 || S > nchunks) return IRBFN_ERR_BAD_ARG;
+  F16Args a;
+  a.x = x; a.img = net->f16_img; a.oscale = net->f16_oscale; a.bias = net->bias; a.out = out; a.gate = net->gate();
+  a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.nchunks = nchunks; a.S = S; a.QG = QG;
+  const int waves = S * QG;
+  const size_t ring = (size_t)waves * 2 * kF16Chunk * f16_rf(net->DC) * 4;
+  const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
+  const size_t lds = ring > red ? ring : red;
+  const long groups = (B + 31) / 32;
+  const int grid = (int)((groups + QG - 1) / QG);
+  int rc;
+  switch (net->DC) {
+    case 3: rc = launch_f16_dc<3>(a, terms, net->bclass, grid, waves * 64, lds, s); break;
+    case 4: rc = launch_f16_dc<4>(a, terms, net->bclass, grid, waves * 64, lds, s); break;
+    case 7: rc = launch_f16_dc<7>(a, terms, net->bclass, grid, waves * 64, lds, s); break;
+    case 8: rc = launch_f16_dc<8>(a, terms, net->bclass, grid, waves * 64, lds, s); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16mfma<D=%d,BC=%d,TERMS=%d,S=%d,QG=%d>", net->DC,
+             net->bclass, terms == 1 ? 1 : 3, S, QG);
+    net->last_grid = grid;
+    net->last_block = waves * 64;
+  }
+  return rc;
+}
+
+}  // namespace irbfn

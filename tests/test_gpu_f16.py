@@ -1,0 +1,146 @@
+"""GPU parity of K1h, the forward with Phi x W on the f16 matrix cores at float32 accuracy
+(irbfn_amd/csrc/rbf_forward_f16.hip), forced with IRBFN_FWD_F16=1: against the float64 oracle, scaled by
+sum_k |phi_k W_k| (the natural error scale of the reduction), and against K1 on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_ckpt_fixture
+from irbfn_amd import configs
+from irbfn_amd.model import WCRBFNet
+from oracle import irbfn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _terms_scale(cfg, p64, x):
+    """sum_k |gamma phi_k W_k| + |bias| per (query, output): float64."""
+    pa = {"params": {"rbf_list": p64["params"]["rbf_list"],
+                     "linear": {"kernel": np.abs(p64["params"]["linear"]["kernel"]), "bias": np.abs(p64["params"]["linear"]["bias"])}}}
+    return orc.wcrbfnet_apply(cfg, pa, x)
+
+
+def _run(net, params, x, **env):
+    with _env(IRBFN_FWD_F16=1, IRBFN_FWD_F16_MINB=65, **env):
+        got = net.apply(params, x)
+        name = net.last_launch()["kernel"]
+    return got, name
+
+
+def test_f16mfma_cfg2_accuracy_and_agreement(gpu):
+    cfg = configs.model_card(2)
+    params = configs.synth_params(2)
+    net = WCRBFNet.from_config(cfg)
+    B = 4096 + 37                                    # ragged tail
+    x = configs.synth_queries(2, B=B)
+    got, name = _run(net, params, x)
+    assert name.startswith("rbf_fwd_f16mfma<D=7,BC=0,TERMS=3"), name
+    p64 = orc.cast_params(params, np.float64)
+    x64 = x.astype(np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x64)
+    scale = _terms_scale(cfg, p64, x64)
+    err = np.abs(got - ref) / scale
+    with _env(IRBFN_FWD_F16=0):
+        k1 = net.apply(params, x)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_qlane")
+    err_k1 = np.abs(k1 - ref) / scale
+    print(f"K1h max/mean err {err.max():.2e}/{err.mean():.2e}   K1 max/mean err {err_k1.max():.2e}/{err_k1.mean():.2e}")
+    # float32-equivalent: no worse than the float32 FMA-chain kernel on the same inputs
+    assert err.max() <= 3e-6 and err.max() <= 2.0 * err_k1.max() and err.mean() <= 1.5 * err_k1.mean(), (err.max(), err_k1.max())
+    assert (np.abs(got - k1) / scale).max() <= 1e-5
+    # every (S, QG) geometry gives the same answer up to the slice summation order
+    for S, QG in ((1, 8), (2, 4), (4, 2), (8, 1), (4, 1), (1, 1)):
+        g2, nm = _run(net, params, x, IRBFN_FWD_F16_S=S, IRBFN_FWD_F16_QG=QG)
+        assert f"S={S},QG={QG}" in nm
+        assert (np.abs(g2 - ref) / scale).max() <= 3e-6, (S, QG)
+    # reduced-precision single-product variant (reporting only): plain f16 operands
+    g1, nm = _run(net, params, x, IRBFN_FWD_F16_TERMS=1)
+    assert "TERMS=1" in nm
+    e1 = (np.abs(g1 - ref) / scale).max()
+    assert 3e-6 < e1 <= 2e-3, e1
+
+
+@pytest.mark.parametrize("run", ["dnmpc_1regions_newdata_oldintloss_nomirror_highk",
+                                 "dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq"])
+@pytest.mark.parametrize("B", [100, 2500])
+def test_f16mfma_on_reference_checkpoints(gpu, run, B):
+    """Trained single-region nets of the reference (gaussian O = 10, inverse_quadratic O = 2; K = 1000 is not
+    a multiple of the 32-centre chunk; bounds make gamma != 1 near the edges)."""
+    cfg, params, x0, out64, *_ = load_ckpt_fixture(run)
+    net = WCRBFNet.from_config(cfg)
+    ns = len(cfg["activation_idx"])
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)])
+    hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    x = np.random.default_rng(B).uniform(lo - 0.02, hi + 0.02, size=(B, cfg["in_features"])).astype(np.float32)
+    x[:64] = x0.astype(np.float32)
+    p32 = orc.cast_params(params, np.float32)
+    got, name = _run(net, p32, x)
+    assert name.startswith("rbf_fwd_f16mfma"), name
+    p64 = orc.cast_params(p32, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    assert (np.abs(got - ref) / scale).max() <= 2e-6
+    gam = orc.region_activation(x.astype(np.float64), cfg["num_regions"], len(cfg["activation_idx"]), cfg["lower_bounds"],
+                                cfg["upper_bounds"], cfg["delta"], cfg["dimension_ranges"])
+    assert gam.min() < 0.9 and gam.max() > 0.99      # the gate is exercised
+
+
+@pytest.mark.parametrize("D,K,O,basis", [(3, 256, 5, "gaussian"), (4, 96, 16, "inverse_multiquadric"),
+                                         (8, 200, 2, "inverse_quadratic"), (7, 33, 1, "gaussian_wide"),
+                                         (5, 64, 7, "inverse_multiquadric")])
+def test_f16mfma_shapes_and_bases(gpu, D, K, O, basis):
+    rng = np.random.default_rng(D * 100 + K)
+    lo, hi = -np.ones(D) * 2, np.ones(D) * 3
+    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": basis, "num_regions": 1,
+           "lower_bounds": [[float(v)] for v in lo], "upper_bounds": [[float(v)] for v in hi],
+           "dimension_ranges": [[0] * D], "activation_idx": list(range(D)), "delta": [20.0] * D}
+    params = {"params": {"rbf_list": {"centers": rng.uniform(lo - 1, hi + 1, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": rng.uniform(-0.5, 1.5, size=(1, K)).astype(np.float32)},
+                         "linear": {"kernel": (rng.normal(size=(K, O)) * rng.choice([1e-3, 1.0, 300.0], size=(1, O))).astype(np.float32),
+                                    "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    B = 1000
+    x = rng.uniform(lo, hi, size=(B, D)).astype(np.float32)
+    got, name = _run(net, params, x)
+    assert name.startswith("rbf_fwd_f16mfma"), name
+    p64 = orc.cast_params(params, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    assert (np.abs(got - ref) / scale).max() <= 2e-6
+
+
+def test_f16mfma_not_used_where_ineligible(gpu):
+    """Multi-region nets, wide outputs and generic bases keep their own kernels even when K1h is forced."""
+    cfg, params, x, *_ = load_ckpt_fixture("dnmpc_128regions")
+    net = WCRBFNet.from_config(cfg)
+    xs = np.repeat(x.astype(np.float32), 4, axis=0)
+    got, name = _run(net, orc.cast_params(params, np.float32), xs)
+    assert name.startswith("rbf_fwd_qlane"), name
+    # NaN queries propagate (IEEE), other rows are unaffected
+    cfg2, p2 = configs.model_card(2), configs.synth_params(2)
+    net2 = WCRBFNet.from_config(cfg2)
+    x2 = configs.synth_queries(2, B=256)
+    clean, _ = _run(net2, p2, x2)
+    x2n = x2.copy()
+    x2n[5, 3] = np.nan
+    dirty, _ = _run(net2, p2, x2n)
+    assert np.isnan(dirty[5]).all()
+    keep = np.ones(256, bool); keep[5] = False
+    np.testing.assert_array_equal(dirty[keep], clean[keep])
