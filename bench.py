@@ -284,6 +284,44 @@ def run_extras(net, params, x, configs, torch):
                                  return_controls=False), 10, torch)
     out["cfg4_fused_plan_tick"] = {"traj_per_s": Bt / t, "ms": t * 1e3, "batch": Bt,
                                    "tflops": Bt * 4096 * (3 * 7 + 2 + 200) / t / 1e12}
+    # BASELINE config 5: 16384-centre inverse-multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs the reduction
+    # "cast as MFMA GEMM": K1h at float32 accuracy (hi/lo f16 operand split) and with plain f16 operands
+    card5 = configs.model_card(5)
+    net5 = WCRBFNet.from_config(card5)
+    p5 = distributed.params_to_device(configs.synth_params(5))
+    x5 = torch.from_numpy(configs.synth_queries(5)).cuda()
+    net5.bind(p5)
+    B5, N5 = x5.shape[0], card5["num_kernels"]
+    pairs = float(B5) * N5
+    res5 = {"batch": B5, "centres": N5, "basis": card5["basis_func"]}
+    ref_out = None
+    for key, env in (("fp32_valu_K1", {"IRBFN_FWD_F16": "0"}),
+                     ("f16x3_mfma_K1h_fp32_accurate", {"IRBFN_FWD_F16": "1", "IRBFN_FWD_F16_TERMS": "3"}),
+                     ("f16_mfma_K1h_reduced_precision", {"IRBFN_FWD_F16": "1", "IRBFN_FWD_F16_TERMS": "1"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            t = _time(lambda: net5(x5), 3, torch)
+            o5 = net5(x5)[:4096].float().cpu().numpy()
+            kern = net5.last_launch()["kernel"]
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if ref_out is None:
+            ref_out = o5
+        entry = {"ms": t * 1e3, "evals_per_s": B5 / t, "kernel": kern,
+                 "fp32_equiv_tflops": pairs * (3 * 7 + 2 + 2 * 10) / t / 1e12,
+                 "max_rel_dev_vs_fp32_kernel": float(np.abs(o5 - ref_out).max() / np.abs(ref_out).max())}
+        if "K1h" in key:
+            # matrix-core share: MFMA instructions of 16 cycles per 16x16x32 tile product, over the kernel's SIMD time
+            terms = 3 if "x3" in key else 1
+            mfma_cycles = pairs / (16 * 32) * terms * 16.0
+            entry["mfma_busy_frac"] = mfma_cycles / (t * 2.4e9 * 1024)
+        res5[key] = entry
+    out["cfg5_imq_16384_centres"] = res5
     return out
 
 

@@ -115,9 +115,15 @@ __device__ __forceinline__ void trans_block(float (&v)[NT]) {
 #undef IRBFN_TRANS_EMIT
 }
 
-// one factor of the smooth indicator: ((tanh(delta*(x-lo))+1)/2) * ((tanh(delta*(hi-x))+1)/2), model.py:83-85
+// one factor of the smooth indicator: ((tanh(delta*(x-lo))+1)/2) * ((tanh(delta*(hi-x))+1)/2), model.py:83-85.
+// (tanh(z)+1)/2 == 1/(1+exp(-2z)): evaluated in that form with v_exp_f32 / v_rcp_f32 (6 instructions instead of
+// ocml's ~35-instruction tanhf; <= 3e-7 relative, and without the float32 cancellation of tanh(z)+1 near z << 0).
+// Saturates to exactly 0 / 1 and propagates NaN like the tanh form.
+__device__ __forceinline__ float half_tanh_plus_one(float z) {
+  return fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * z));      // 2*log2(e)
+}
 __device__ __forceinline__ float gate_factor(float xv, float lo, float hi, float delta) {
-  return ((tanhf(delta * (xv - lo)) + 1.0f) * 0.5f) * ((tanhf(delta * (hi - xv)) + 1.0f) * 0.5f);
+  return half_tanh_plus_one(delta * (xv - lo)) * half_tanh_plus_one(delta * (hi - xv));
 }
 
 }  // namespace irbfn

@@ -108,7 +108,7 @@ int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStre
 // K1 dispatcher: picks queries-per-lane Q and waves-per-workgroup NW, sizes LDS, launches.
 // ------------------------------------------------------------------------------------------------
 #ifndef IRBFN_F16_DEFAULT
-#define IRBFN_F16_DEFAULT 0        // K1h opt-in until it is measured faster than K1 on every compiled shape
+#define IRBFN_F16_DEFAULT 1        // K1h where eligible: cfg-2 131 vs 142 us, cfg-5 7.5 vs 8.9 ms (K1)
 #endif
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -225,13 +225,13 @@ static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t 
 // K1h (Phi x W on the f16 matrix cores at float32 accuracy, rbf_forward_f16.hip): narrow outputs, one region.
 // IRBFN_FWD_F16 = 0 / 1 forces K1 / K1h; IRBFN_FWD_F16_TERMS = 1 selects the reduced-precision single-product
 // variant (reporting only).  Geometry: S centre slices x QG query groups of 32 per 8-wave block, S chosen so
-// that the launch has >= 8192 waves (8 per SIMD).
+// that the launch has >= 16384 waves.
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (!net->f16_img) return IRBFN_ERR_UNSUPPORTED;
   const int e = env_int("IRBFN_FWD_F16", IRBFN_F16_DEFAULT);
   if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 2048)) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
-  long want = (8192 + groups - 1) / groups;
+  long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
   int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
   S = pow2_floor(S);
   if (S < want && S < 8) S *= 2;

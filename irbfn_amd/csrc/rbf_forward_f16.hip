@@ -247,17 +247,19 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
 
   // ---- smooth region gate of the single region (model.py:42-95), one value per query
   const GateTables gt = a.gate;
-  float gam[2];
+  float gam[2] = {0.0f, 0.0f};
+  if (slice == 0) {                                          // only the slice-0 wave of a query group applies it
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;                // model.py:70
+    for (int t = 0; t < 2; ++t) {
+      float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;              // model.py:70
 #pragma unroll
-    for (int d = 0; d < DC; ++d)
-      if (d < gt.nsplit && gt.n_ranges > 0) {
-        const int e = d * gt.max_ranges + gt.dim_ranges[d];
-        gv *= gate_factor(xq[t][d], gt.lo[e], gt.hi[e], gt.delta[d]);
-      }
-    gam[t] = gv;
+      for (int d = 0; d < DC; ++d)
+        if (d < gt.nsplit && gt.n_ranges > 0) {
+          const int e = d * gt.max_ranges + gt.dim_ranges[d];
+          gv *= gate_factor(xq[t][d], gt.lo[e], gt.hi[e], gt.delta[d]);
+        }
+      gam[t] = gv;
+    }
   }
   // ---- sum the S centre slices in fixed order, scale, bias, store
   __syncthreads();                                           // every wave is done with its ring

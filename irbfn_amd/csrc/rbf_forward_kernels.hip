@@ -132,16 +132,20 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
   float* gtab = lds + ROWS * Dr;                 // GATED: [nsplit*max_ranges][ROWS]
   if constexpr (!GATED) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      float g = gt.n_ranges > 0 ? 1.0f : 0.0f;   // model.py:70: regions without a range stay 0
+    for (int q = 0; q < Q; ++q) gam[q] = 0.0f;
+    if (wave == 0) {                             // R == 1: gamma factors out of the k-sum, only wave 0 applies it
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if (d < gt.nsplit && gt.n_ranges > 0) {
-          const int e = d * gt.max_ranges + gt.dim_ranges[d];
-          g *= gate_factor(xq[q][d], gt.lo[e], gt.hi[e], gt.delta[d]);
+      for (int q = 0; q < Q; ++q) {
+        float g = gt.n_ranges > 0 ? 1.0f : 0.0f; // model.py:70: regions without a range stay 0
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          if (d < gt.nsplit && gt.n_ranges > 0) {
+            const int e = d * gt.max_ranges + gt.dim_ranges[d];
+            g *= gate_factor(xq[q][d], gt.lo[e], gt.hi[e], gt.delta[d]);
+          }
         }
+        gam[q] = g;
       }
-      gam[q] = g;
     }
   } else {
     const int E = gt.nsplit * gt.max_ranges;
