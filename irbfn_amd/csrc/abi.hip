@@ -81,7 +81,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   if (mfma_eligible(net)) alloc((void**)&net->recm, (size_t)net->Npad * mfma_record_floats(D, O) * sizeof(float));
   if (f16_eligible(net)) {
     alloc((void**)&net->f16_img, f16_image_bytes(net));
-    alloc((void**)&net->f16_oscale, 16 * sizeof(float));
+    alloc((void**)&net->f16_oscale, 128 * sizeof(float));
   }
   alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
   alloc((void**)&net->small_ticket, small_ticket_count() * sizeof(unsigned int));

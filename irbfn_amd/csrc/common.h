@@ -69,7 +69,7 @@ struct irbfn_net {
   float* recm;  // [Npad][CW + 16*NT] records of the MFMA forward (K1m); NULL if not eligible
   int Npad;     // N rounded up to a multiple of 16 (MFMA chunk)
   unsigned char* f16_img;   // chunk images of the f16-split matrix-core forward (K1h); NULL if not eligible
-  float* f16_oscale;        // [16] per-output power-of-two scale of the K1h weight split
+  float* f16_oscale;        // [128] per-output power-of-two scale of the K1h weight split
   float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
   unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs

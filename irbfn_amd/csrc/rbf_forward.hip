@@ -231,6 +231,13 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   const int e = env_int("IRBFN_FWD_F16", IRBFN_F16_DEFAULT);
   if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 2048)) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
+  if (net->O > 16) {
+    // wide outputs: block-shared W stream; SW = centre slices per block so that the grid covers the 256 CUs
+    int SW = 1;
+    while (SW < 4 && (groups * SW + 7) / 8 < 256) SW *= 2;
+    SW = env_int("IRBFN_FWD_F16_S", SW);
+    return launch_forward_f16(net, x, out, B, SW, 8 / (SW < 1 ? 1 : SW), 3, s);
+  }
   long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
   int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
   S = pow2_floor(S);
@@ -252,8 +259,8 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
     const int rc = launch_forward_small(net, x, out, B, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   }
-  if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
   if (try_forward_f16(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
+  if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
   FwdArgs a;
   fill_args(net, a, x, out, B);
   return run_forward(net, a, false, s);

@@ -42,12 +42,13 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 constexpr int kF16Chunk = 32;                    // centres per chunk = MFMA K
 constexpr int kF16WBytes = 4 * 16 * 8 * 2;       // one W part of a chunk: [g][n][8] halfs = 1 KiB
 constexpr int f16_rf(int DC) { return DC <= 3 ? 4 : (DC <= 7 ? 8 : 12); }    // floats per centre record
-constexpr int f16_chunk_bytes(int DC) { return kF16Chunk * f16_rf(DC) * 4 + 2 * kF16WBytes; }
+constexpr int f16_chunk_bytes(int DC, int NT = 1) { return kF16Chunk * f16_rf(DC) * 4 + NT * 2 * kF16WBytes; }
+// chunk image: rec[32][RF] floats, then per column tile ct < NT: Whi[ct] (1 KiB), Wlo[ct] (1 KiB)
 
 struct F16Args {
   const float* __restrict__ x;            // [B][Dreal]
   const unsigned char* __restrict__ img;  // [nchunks][chunk image]
-  const float* __restrict__ oscale;       // [16] s_o
+  const float* __restrict__ oscale;       // [16 * NT] s_o
   const float* __restrict__ bias;         // [OP]
   float* __restrict__ out;                // [B][O]
   GateTables gate;
@@ -85,16 +86,14 @@ __global__ __launch_bounds__(256) void f16_colscale_kernel(const float* __restri
 __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                        const float* __restrict__ kernel, const float* __restrict__ oscale,
                                                        unsigned char* __restrict__ img, int N, int K, int D, int RF,
-                                                       int O, int bclass, float gscale, int nchunks) {
+                                                       int O, int NT, int bclass, float gscale, int nchunks) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nchunks * kF16Chunk) return;
   const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
   const int n = idx;                                         // centre index (R == 1: n == k)
-  const size_t cb = (size_t)kF16Chunk * RF * 4 + 2 * kF16WBytes;
+  const size_t cb = (size_t)kF16Chunk * RF * 4 + (size_t)NT * 2 * kF16WBytes;
   unsigned char* p = img + (size_t)c * cb;
   float* rec = reinterpret_cast<float*>(p) + kk * RF;
-  __half* wh = reinterpret_cast<__half*>(p + (size_t)kF16Chunk * RF * 4);
-  __half* wl = wh + kF16WBytes / 2;
   const bool real = n < N;
   for (int j = 0; j < RF - 1; ++j) rec[j] = (real && j < D) ? centers[(size_t)n * D + j] : 0.0f;
   float sc = 0.0f;                                           // padding centre: phi' = 2^14 exactly, W' = 0
@@ -106,13 +105,18 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
   }
   rec[RF - 1] = sc;
   const int g = kk >> 3, j = kk & 7;
-  for (int o = 0; o < 16; ++o) {
-    float w = 0.0f;
-    if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
-    const __half h = __float2half_rn(w);
-    const __half l = __float2half_rn(w - __half2float(h));
-    wh[(g * 16 + o) * 8 + j] = h;
-    wl[(g * 16 + o) * 8 + j] = l;
+  for (int ct = 0; ct < NT; ++ct) {
+    __half* wh = reinterpret_cast<__half*>(p + (size_t)kF16Chunk * RF * 4 + (size_t)ct * 2 * kF16WBytes);
+    __half* wl = wh + kF16WBytes / 2;
+    for (int oo = 0; oo < 16; ++oo) {
+      const int o = ct * 16 + oo;
+      float w = 0.0f;
+      if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
+      const __half h = __float2half_rn(w);
+      const __half l = __float2half_rn(w - __half2float(h));
+      wh[(g * 16 + oo) * 8 + j] = h;
+      wl[(g * 16 + oo) * 8 + j] = l;
+    }
   }
 }
 
@@ -287,26 +291,262 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
   }
 }
 
+// ---- wide outputs (16 < O <= 128): NT = ceil(O/16) column tiles ----------------------------------------------
+// Same mathematics and operand split; the W operands of a chunk (NT x 2 KiB) are too many to stream per wave,
+// so the 8 waves of a block are SW centre slices x QG query groups and the QG waves of a slice SHARE one
+// double-buffered LDS image of the slice's current chunk (cooperative 16-byte copies, one barrier per step).
+// Per step a wave computes the distances / basis / split of its 32 queries x 32 centres, then for every
+// column tile reads (bh, bl) from LDS and issues 2 row tiles x 3 terms MFMAs.
+template <int DC, int BC, int NT>
+__global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RF = f16_rf(DC);
+  constexpr int RECB = kF16Chunk * RF * 4;
+  constexpr int CB = f16_chunk_bytes(DC, NT);
+  constexpr int NV = CB / 16;                                // 16-byte pieces per chunk image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int SW = a.S, QG = a.QG;
+  const int slice = wave / QG, qg = wave % QG;               // the QG waves of a slice are adjacent
+  const int g = lane >> 4, n = lane & 15;
+  const long q0 = ((long)blockIdx.x * QG + qg) * 32;
+  float xq[2][DC];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long q = q0 + t * 16 + n;
+    q = q < a.B ? q : a.B - 1;
+    q = q < 0 ? 0 : q;
+#pragma unroll
+    for (int i = 0; i < DC; ++i) xq[t][i] = i < a.Dreal ? a.x[q * a.Dreal + i] : 0.0f;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < DC; ++i) asm volatile("" : "+v"(xq[t][i]));
+  const int nsteps = (a.nchunks + SW - 1) / SW;              // chunks per slice (the last slice may have fewer)
+  const int c0 = slice * nsteps;
+  const int c1 = (c0 + nsteps) < a.nchunks ? (c0 + nsteps) : a.nchunks;
+  unsigned char* stream = lds + (size_t)slice * 2 * CB;      // this slice's two chunk buffers
+  const int st = qg * 64 + lane;                             // thread index within the slice's copy team
+  const int team = QG * 64;
+  constexpr int MAXP = (NV + 127) / 128;                     // pieces per thread at the smallest team (QG = 2)
+  u4_t pre[MAXP];
+  auto fetch = [&](int c) {
+    const u4_t* src = reinterpret_cast<const u4_t*>(a.img + (size_t)c * CB);
+#pragma unroll
+    for (int v = 0; v < MAXP; ++v)
+      if (v * team + st < NV) pre[v] = src[v * team + st];
+  };
+  auto stash = [&](unsigned char* dst) {
+#pragma unroll
+    for (int v = 0; v < MAXP; ++v)
+      if (v * team + st < NV) reinterpret_cast<u4_t*>(dst)[v * team + st] = pre[v];
+  };
+  f4_t acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[t][ct] = f4_t{0, 0, 0, 0};
+  if (c0 < c1) { fetch(c0); stash(stream); }
+  __syncthreads();
+  for (int i = 0; i < nsteps; ++i) {
+    const int c = c0 + i;
+    const unsigned char* cur = stream + (i & 1) * CB;
+    unsigned char* nxt = stream + ((i + 1) & 1) * CB;
+    const bool has_next = c + 1 < c1;
+    if (has_next) fetch(c + 1);
+    if (c < c1) {
+      float t16[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* rp = reinterpret_cast<const float*>(cur) + (8 * g + j) * RF;
+        float r[RF];
+#pragma unroll
+        for (int v = 0; v < RF / 4; ++v) {
+          const f4_t rr = *reinterpret_cast<const f4_t*>(rp + 4 * v);
+          r[4 * v] = rr.x; r[4 * v + 1] = rr.y; r[4 * v + 2] = rr.z; r[4 * v + 3] = rr.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float r2 = 0.0f;
+#pragma unroll
+          for (int d = 0; d < DC; ++d) {
+            const float df = xq[t][d] - r[d];
+            r2 = __builtin_fmaf(df, df, r2);
+          }
+          t16[t * 8 + j] = f16_arg<BC>(r2, r[RF - 1]);
+        }
+      }
+      trans_block<BC, 16>(t16);
+      h8_t ah[2], al[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float p0 = t16[t * 8 + 2 * jj], p1 = t16[t * 8 + 2 * jj + 1];
+          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
+          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
+          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+          const h2_t ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
+          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
+          al[t][2 * jj] = (_Float16)ll[0]; al[t][2 * jj + 1] = (_Float16)ll[1];
+        }
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const h8_t bh = *reinterpret_cast<const h8_t*>(cur + RECB + ct * 2 * kF16WBytes + lane * 16);
+        const h8_t bl = *reinterpret_cast<const h8_t*>(cur + RECB + ct * 2 * kF16WBytes + kF16WBytes + lane * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][ct], 0, 0, 0);
+          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][ct], 0, 0, 0);
+          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][ct], 0, 0, 0);
+        }
+      }
+    }
+    if (has_next) stash(nxt);
+    __syncthreads();
+  }
+
+  const GateTables gt = a.gate;
+  float gam[2] = {0.0f, 0.0f};
+  if (slice == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;
+#pragma unroll
+      for (int d = 0; d < DC; ++d)
+        if (d < gt.nsplit && gt.n_ranges > 0) {
+          const int e = d * gt.max_ranges + gt.dim_ranges[d];
+          gv *= gate_factor(xq[t][d], gt.lo[e], gt.hi[e], gt.delta[d]);
+        }
+      gam[t] = gv;
+    }
+  }
+  // slices summed per column tile in fixed order through LDS (the streams are dead: the loop ended on a barrier)
+  float* red = reinterpret_cast<float*>(lds);                // [SW][QG][2][4][64]
+  float* gl = red + (size_t)SW * QG * 2 * 4 * 64;            // [QG][32]
+  if (slice == 0 && g == 0) { gl[qg * 32 + n] = gam[0]; gl[qg * 32 + 16 + n] = gam[1]; }
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((slice * QG + qg) * 2 + t) * 4 + r) * 64 + lane] = acc[t][ct][r];
+    __syncthreads();
+    const int o = ct * 16 + n;
+    if (slice == 0 && o < a.O) {
+      const float sc = a.oscale[o] * 6.103515625e-05f;
+      const float bi = a.bias[o];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.0f;
+          for (int s2 = 0; s2 < SW; ++s2) v += red[(((s2 * QG + qg) * 2 + t) * 4 + r) * 64 + lane];
+          const int row = t * 16 + 4 * g + r;
+          const long q = q0 + row;
+          if (q < a.B) a.out[q * a.O + o] = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);
+        }
+    }
+    __syncthreads();
+  }
+}
+
+
 // ---- host side -------------------------------------------------------------------------------------------
 bool f16_eligible(const irbfn_net* net) {
-  return net->R == 1 && net->bclass != BC_GENERIC && net->O <= 16 && (net->DC == 3 || net->DC == 4 || net->DC == 7 || net->DC == 8);
+  return net->R == 1 && net->bclass != BC_GENERIC && net->O <= 128 && (net->DC == 3 || net->DC == 4 || net->DC == 7 || net->DC == 8);
 }
+
+static int f16_nt(const irbfn_net* net) { return (net->O + 15) / 16; }
 
 size_t f16_image_bytes(const irbfn_net* net) {
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
-  return (size_t)nchunks * f16_chunk_bytes(net->DC);
+  return (size_t)nchunks * f16_chunk_bytes(net->DC, f16_nt(net));
 }
 
 int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
-  hipLaunchKernelGGL(f16_colscale_kernel, dim3(16), dim3(256), 0, s, kernel, net->f16_oscale, net->K, net->O);
+  const int NT = f16_nt(net);
+  hipLaunchKernelGGL(f16_colscale_kernel, dim3(16 * NT), dim3(256), 0, s, kernel, net->f16_oscale, net->K, net->O);
   IRBFN_HIP_CHECK(hipGetLastError());
   const int total = nchunks * kF16Chunk;
   hipLaunchKernelGGL(f16_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, centers, log_sigs, kernel,
-                     net->f16_oscale, net->f16_img, net->N, net->K, net->D, f16_rf(net->DC), net->O, net->bclass,
+                     net->f16_oscale, net->f16_img, net->N, net->K, net->D, f16_rf(net->DC), net->O, NT, net->bclass,
                      gauss_scale(net->basis), nchunks);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
+}
+
+template <int DC, int NT>
+static int launch_f16w_bc(const F16Args& a, int bc, int grid, size_t lds, hipStream_t s) {
+#define IRBFN_WCASE(BCV)                                                                                      \
+  case BCV: {                                                                                                 \
+    auto k = rbf_fwd_f16mfma_wide<DC, BCV, NT>;                                                               \
+    if (lds > 48 * 1024) {                                                                                    \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }                               \
+    }                                                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                  \
+    break;                                                                                                    \
+  }
+  switch (bc) {
+    IRBFN_WCASE(BC_GAUSS)
+    IRBFN_WCASE(BC_IQ)
+    IRBFN_WCASE(BC_IMQ)
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+#undef IRBFN_WCASE
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int DC>
+static int launch_f16w_dc(const F16Args& a, int NT, int bc, int grid, size_t lds, hipStream_t s) {
+  switch (NT) {
+    case 2: return launch_f16w_bc<DC, 2>(a, bc, grid, lds, s);
+    case 3: return launch_f16w_bc<DC, 3>(a, bc, grid, lds, s);
+    case 4: return launch_f16w_bc<DC, 4>(a, bc, grid, lds, s);
+    case 5: return launch_f16w_bc<DC, 5>(a, bc, grid, lds, s);
+    case 6: return launch_f16w_bc<DC, 6>(a, bc, grid, lds, s);
+    case 7: return launch_f16w_bc<DC, 7>(a, bc, grid, lds, s);
+    case 8: return launch_f16w_bc<DC, 8>(a, bc, grid, lds, s);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+// SW centre slices (1, 2 or 4) x QG = 8 / SW query groups of 32 per 512-thread block
+static int launch_forward_f16_wide(irbfn_net* net, const float* x, float* out, int64_t B, int SW, hipStream_t s) {
+  const int NT = f16_nt(net);
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  if (SW != 1 && SW != 2 && SW != 4) return IRBFN_ERR_BAD_ARG;
+  while (SW > 1 && nchunks / SW < 2) SW /= 2;
+  const int QG = 8 / SW;
+  F16Args a;
+  a.x = x; a.img = net->f16_img; a.oscale = net->f16_oscale; a.bias = net->bias; a.out = out; a.gate = net->gate();
+  a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.nchunks = nchunks; a.S = SW; a.QG = QG;
+  const size_t stream = (size_t)SW * 2 * f16_chunk_bytes(net->DC, NT);
+  const size_t red = ((size_t)8 * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
+  const size_t lds = stream > red ? stream : red;
+  if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  const long groups = (B + 31) / 32;
+  const int grid = (int)((groups + QG - 1) / QG);
+  int rc;
+  switch (net->DC) {
+    case 3: rc = launch_f16w_dc<3>(a, NT, net->bclass, grid, lds, s); break;
+    case 4: rc = launch_f16w_dc<4>(a, NT, net->bclass, grid, lds, s); break;
+    case 7: rc = launch_f16w_dc<7>(a, NT, net->bclass, grid, lds, s); break;
+    case 8: rc = launch_f16w_dc<8>(a, NT, net->bclass, grid, lds, s); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16mfma_wide<D=%d,BC=%d,NT=%d,SW=%d,QG=%d>", net->DC,
+             net->bclass, NT, SW, QG);
+    net->last_grid = grid;
+    net->last_block = 512;
+  }
+  return rc;
 }
 
 template <int DC, int TERMS>
@@ -329,6 +569,7 @@ static int launch_f16_dc(const F16Args& a, int terms, int bc, int grid, int bloc
 // S = centre slices per query group, QG = query groups (of 32) per block; S * QG <= 8 waves
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s) {
   if (!net->f16_img || !f16_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  if (net->O > 16) return launch_forward_f16_wide(net, x, out, B, S, s);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   if (S < 1 || QG < 1 || S * QG > 8 || S > nchunks) return IRBFN_ERR_BAD_ARG;
   F16Args a;

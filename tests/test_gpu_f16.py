@@ -144,3 +144,31 @@ def test_f16mfma_not_used_where_ineligible(gpu):
     assert np.isnan(dirty[5]).all()
     keep = np.ones(256, bool); keep[5] = False
     np.testing.assert_array_equal(dirty[keep], clean[keep])
+
+
+@pytest.mark.parametrize("O,SW", [(100, 2), (100, 1), (100, 4), (20, 2), (64, 1), (128, 4)])
+def test_f16mfma_wide_outputs(gpu, O, SW):
+    """16 < O <= 128 (50-step control sequences, O = 100): block-shared W stream, NT column tiles."""
+    rng = np.random.default_rng(O + SW)
+    D, K = 7, 300
+    cfg = dict(configs.model_card(4), num_kernels=K, out_features=O)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(-1, 8, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": rng.uniform(0.0, 2.0, size=(1, K)).astype(np.float32)},
+                         "linear": {"kernel": rng.normal(0, 0.3, size=(K, O)).astype(np.float32),
+                                    "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    B = 777
+    x = configs.synth_queries(4, B=B)
+    got, name = _run(net, params, x, IRBFN_FWD_F16_S=SW)
+    assert name.startswith("rbf_fwd_f16mfma_wide") and f"SW={SW}" in name, name
+    p64 = orc.cast_params(params, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    assert got.shape == (B, O)
+    with _env(IRBFN_FWD_F16=0):
+        other = net.apply(params, x)
+        assert not net.last_launch()["kernel"].startswith("rbf_fwd_f16")
+    err, err_other = (np.abs(got - ref) / scale).max(), (np.abs(other - ref) / scale).max()
+    # float32-equivalent: the error is that of the shared float32 distance / basis arithmetic
+    assert err <= max(2e-6, 2.0 * err_other), (err, err_other)
+    assert (np.abs(got - other) / scale).max() <= 1e-5
