@@ -35,6 +35,7 @@ UNITS = [
     ("rbf_forward_f16.hip", "rbf_fwd_f16.o", []),
     ("rbf_forward_small.hip", "rbf_fwd_small.o", []),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
+    ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     ("rollout.hip", "rollout.o", []),
     ("rollout_vjp.hip", "rollout_vjp.o", []),
     ("train_step.hip", "train_step.o", []),

@@ -16,6 +16,11 @@
 // without atomics: LDS across the 4 waves, a [slice][value][centre] slab in the workspace, then a
 // fixed-order reduce kernel -> bitwise reproducible gradients.
 #include "rbf_forward.h"
+#include "rbf_vjp_f16.h"
+
+#ifndef IRBFN_VJP_F16_DEFAULT
+#define IRBFN_VJP_F16_DEFAULT 1     // K2h where eligible (cfg-3: 336 vs 394 us)
+#endif
 
 namespace irbfn {
 
@@ -200,8 +205,11 @@ __global__ void vjp_reduce_kernel(const float* __restrict__ part, float* __restr
 
 // d bias[o] = sum_b g[b,o]: per-block column sums, then one block finishes (fixed order)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, float* __restrict__ part,
-                                                              long B, int O, long rows_per_block) {
+                                                              long B, int O, long rows_per_block,
+                                                              float* __restrict__ bmax) {
   extern __shared__ float sm[];                // [256]
+  __shared__ float smax[256];
+  float mx = 0.0f;                             // max |g| of this block's rows (K2h operand scale), NaN wins
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   r1 = r1 < B ? r1 : B;
@@ -214,7 +222,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int t = threadIdx.x;
     float s = 0.0f;
     if (t < stride)
-      for (long i = t; i < total; i += stride) s += base[i];
+      for (long i = t; i < total; i += stride) {
+        const float v = base[i];
+        s += v;
+        const float av = fabsf(v);
+        mx = (av > mx || av != av) ? av : mx;
+      }
     sm[t] = t < stride ? s : 0.0f;
     __syncthreads();
     if (t < O) {
@@ -225,9 +238,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   } else {
     for (int o = threadIdx.x; o < O; o += 256) {
       float s = 0.0f;
-      for (long rr = 0; rr < r1 - r0; ++rr) s += base[rr * O + o];
+      for (long rr = 0; rr < r1 - r0; ++rr) {
+        const float v = base[rr * O + o];
+        s += v;
+        const float av = fabsf(v);
+        mx = (av > mx || av != av) ? av : mx;
+      }
       part[(size_t)blockIdx.x * O + o] = s;
     }
+  }
+  if (bmax) {                                  // block-uniform
+    smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) {
+        const float o2 = smax[threadIdx.x + w], m2 = smax[threadIdx.x];
+        smax[threadIdx.x] = (o2 > m2 || o2 != o2) ? o2 : m2;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) bmax[blockIdx.x] = smax[0];
   }
 }
 
@@ -250,9 +280,16 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 struct VjpPlan {
   int groups, QSB, per_wave, Npad, V, bias_blocks;
   long rows_per_block;
-  size_t off_gamma, off_part, off_bias, off_qrec, total;
+  size_t off_gamma, off_part, off_bias, off_qrec, off_qblk, off_misc, total;
   int QS;
+  bool use_h;      // K2h (matrix-core VJP) instead of K2
+  int CT;
 };
+
+static int vjp_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   VjpPlan p;
@@ -279,6 +316,20 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   p.off_bias = off;  off += al((size_t)p.bias_blocks * net->O * sizeof(float));
   p.QS = (net->DC + 1 + net->OP + 3) & ~3;
   p.off_qrec = off;  off += al((size_t)B * p.QS * sizeof(float));
+  // K2h: packed 32-query blocks + (absmax, scales); IRBFN_VJP_F16 = 0 / 1 forces K2 / K2h
+  p.use_h = vjph_eligible(net) && B >= 2048 && vjp_env_int("IRBFN_VJP_F16", IRBFN_VJP_F16_DEFAULT) != 0;
+  p.CT = vjp_env_int("IRBFN_VJP_F16_CT", 2) == 4 ? 4 : 2;
+  p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * vjph_block_bytes(net) : 0);
+  p.off_misc = off;  off += al((size_t)(p.bias_blocks + 8) * sizeof(float));
+  if (p.use_h) {
+    // fewer, longer query slices than K2 (3 waves per SIMD resident): halves the slab traffic of the reduce kernel
+    const long gh = (net->N + 16 * p.CT - 1) / (16 * p.CT);
+    long q2 = (6144 + gh * 4 - 1) / (gh * 4);
+    const long nqb = (B + 31) / 32;
+    if (q2 * 4 > nqb) q2 = (nqb + 3) / 4;
+    if (q2 < 1) q2 = 1;
+    if (q2 < p.QSB) p.QSB = (int)q2;          // never more slabs than were allocated above
+  }
   p.total = off;
   return p;
 }
@@ -354,6 +405,23 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   float* gamma = reinterpret_cast<float*>(base + p.off_gamma);
   float* part = reinterpret_cast<float*>(base + p.off_part);
   float* bpart = reinterpret_cast<float*>(base + p.off_bias);
+  const long total_h = n_c + n_l + n_k;
+  if (p.use_h) {
+    float* bmax = reinterpret_cast<float*>(base + p.off_misc);           // [bias_blocks] max |g| per block
+    float* scales = bmax + p.bias_blocks;                                // [2]
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
+                       (long)B, net->O, p.rows_per_block, bmax);
+    IRBFN_HIP_CHECK(hipGetLastError());
+    int rch = launch_vjp_f16(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks,
+                             scales, part, p.QSB, p.Npad, p.CT, s);
+    if (rch != IRBFN_OK) return rch;
+    hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total_h + 255) / 256)), dim3(256), 0, s, part, g_centers,
+                       g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
+    IRBFN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
+    IRBFN_HIP_CHECK(hipGetLastError());
+    return IRBFN_OK;
+  }
 
   float* qrec = reinterpret_cast<float*>(base + p.off_qrec);
   {
@@ -385,7 +453,7 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
                      g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
   IRBFN_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
-                     (long)B, net->O, p.rows_per_block);
+                     (long)B, net->O, p.rows_per_block, (float*)nullptr);
   IRBFN_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
   IRBFN_HIP_CHECK(hipGetLastError());

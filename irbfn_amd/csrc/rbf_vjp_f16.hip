@@ -1,0 +1,383 @@
+// K2h: parameter VJP of the single-region RBF net with its two GEMM-shaped pieces on the f16 matrix cores at
+// float32 accuracy (same hi/lo operand split as the forward kernel K1h, rbf_forward_f16.hip):
+//     hbar[q,k] = sum_o g[q,o] W[k,o]        (v_mfma_f32_16x16x16_f16: rows = queries, cols = centres, k = outputs)
+//     dW[k,o]   = sum_q gamma_q phi[q,k] g[q,o]   (v_mfma_f32_16x16x32_f16: rows = outputs, cols = centres, k = queries)
+// and everything else (distances, basis, d centers, d log_sigs; SURVEY App. A.2, jax.value_and_grad at
+// scripts/train_nmpc.py:297-298) on the VALU.  Replaces rbf_vjp_kernel (K2) where eligible and writes the
+// same slab format, so vjp_reduce_kernel and the bias column sums are shared.
+//
+// Layout: a wave owns CT tiles of 16 centres and a slice of the 32-query blocks.  Lane (g = l >> 4, n = l & 15)
+// holds centre n of every tile (coordinates, scales and gradient accumulators in VGPRs for the whole launch) and,
+// per query block, the 8 queries qid_g(p) = 16 (p >> 2) + 4 g + (p & 3): exactly the rows the 16x16x16 MFMA
+// returns to this lane (hbar needs no transpose) and, read as k = 8 g + p, a valid B operand of the dW MFMA.
+// Query blocks come pre-packed (vjp_pack_blocks_kernel): x and gamma as float rows for broadcast LDS reads,
+// g as ready-made f16 (hi, lo) MFMA operands in both orientations.
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rbf_forward.h"
+#include "rbf_vjp_f16.h"
+
+namespace irbfn {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// ---- pre-pass ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow2_ceil_scale(float mx) {
+  if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;          // zero / Inf / NaN: unscaled
+  int e;
+  (void)frexpf(mx, &e);
+  return ldexpf(1.0f, e);
+}
+
+// one 64-lane block per 32-query block
+__global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                             const float* __restrict__ bmax, int nbmax,
+                                                             const float* __restrict__ oscale,
+                                                             unsigned char* __restrict__ qblk, float* __restrict__ scales,
+                                                             GateTables gt, long B, int D, int RFQ, int O) {
+  const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+  const long q0 = (long)blockIdx.x * 32;
+  const int blkb = 32 * RFQ * 4 + 4096;
+  unsigned char* p = qblk + (size_t)blockIdx.x * blkb;
+  float mx = 0.0f;                             // max |g| over the batch from the per-block maxima of colsum_partial_kernel
+  for (int i = lane; i < nbmax; i += 64) {
+    const float v = bmax[i];
+    mx = (v > mx || v != v) ? v : mx;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o2 = __shfl_xor(mx, off);
+    mx = (o2 > mx || o2 != o2) ? o2 : mx;
+  }
+  const float sg = pow2_ceil_scale(mx);
+  float somax = 0.0f;
+  for (int o = 0; o < O; ++o) somax = fmaxf(somax, oscale[o]);
+  const float sh = sg * somax;
+  if (blockIdx.x == 0 && lane == 0) { scales[0] = sg; scales[1] = sh; }
+  // x rows + gate (model.py:42-95, single region)
+  if (lane < 32) {
+    const long q = q0 + lane;
+    float* row = reinterpret_cast<float*>(p) + lane * RFQ;
+    float gm = 0.0f;
+    if (q < B) {
+      gm = gt.n_ranges > 0 ? 1.0f : 0.0f;
+      for (int d = 0; d < gt.nsplit && gt.n_ranges > 0; ++d) {
+        const int e = d * gt.max_ranges + gt.dim_ranges[d];
+        gm *= gate_factor(x[q * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+      }
+    }
+    for (int j = 0; j < RFQ - 1; ++j) row[j] = (q < B && j < D) ? x[q * D + j] : 0.0f;
+    row[RFQ - 1] = gm;
+  }
+  h4v* gA = reinterpret_cast<h4v*>(p + 32 * RFQ * 4);                // [s][part][lane] x 4 halfs
+  h8v* gT = reinterpret_cast<h8v*>(p + 32 * RFQ * 4 + 2048);         // [part][lane] x 8 halfs
+  // A operand of the hbar MFMA: rows = queries 16 s + n, k = outputs 4 g + j, scaled by s_o / s_h
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const long q = q0 + 16 * s + n;
+    h4v hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 4 * g + j;
+      float v = 0.0f;
+      if (q < B && o < O) v = gout[q * O + o] * (oscale[o] / sh);
+      const _Float16 h = (_Float16)v;
+      hi[j] = h;
+      lo[j] = (_Float16)(v - (float)h);
+    }
+    gA[(s * 2 + 0) * 64 + lane] = hi;
+    gA[(s * 2 + 1) * 64 + lane] = lo;
+  }
+  // A operand of the dW MFMA: rows = outputs n, k = 8 g + j <-> query qid_g(j), scaled by 1 / s_g
+  h8v thi, tlo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long q = q0 + 16 * (j >> 2) + 4 * g + (j & 3);
+    float v = 0.0f;
+    if (q < B && n < O) v = gout[q * O + n] / sg;
+    const _Float16 h = (_Float16)v;
+    thi[j] = h;
+    tlo[j] = (_Float16)(v - (float)h);
+  }
+  gT[0 * 64 + lane] = thi;
+  gT[1 * 64 + lane] = tlo;
+}
+
+// ---- main kernel -------------------------------------------------------------------------------------------
+struct VjpHArgs {
+  const unsigned char* __restrict__ qblk;   // [nqb][block image]
+  const float* __restrict__ scales;         // [0] = s_g, [1] = s_h
+  const float* __restrict__ rec;            // [N][S] K1 records: c[DC], scale, W[OP]
+  const float* __restrict__ sig2;           // [N]
+  const float* __restrict__ oscale;         // [O]
+  float* __restrict__ part;                 // [QSB][V][Npad]
+  long nqb;
+  int O, OP, N, S, Npad, basis, bpw;
+  float gscale;
+};
+
+template <int DC, int BC, int CT>
+__global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const VjpHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RFQ = vjph_rfq(DC);
+  constexpr int QXB = 32 * RFQ * 4;
+  constexpr int BLKB = QXB + 4096;
+  constexpr int NV = BLKB / 16;
+  constexpr int NP = (NV + 63) / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int cb = blockIdx.x * 16 * CT;
+  const float sg = a.scales[0], sh = a.scales[1];
+
+  float c[CT][DC], sc[CT], s2[CT];
+  h4v wth[CT], wtl[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    int cid = cb + ct * 16 + n;
+    cid = cid < a.N ? cid : a.N - 1;
+    const float* rp = a.rec + (size_t)cid * a.S;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) c[ct][j] = rp[j];
+    sc[ct] = rp[DC];
+    s2[ct] = a.sig2[cid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 4 * g + j;
+      const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] : 0.0f;
+      const _Float16 h = (_Float16)w;
+      wth[ct][j] = h;
+      wtl[ct][j] = (_Float16)(w - (float)h);
+    }
+  }
+  float gc[CT][DC], gls[CT];
+  f4v dW[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    gls[ct] = 0.0f;
+    dW[ct] = f4v{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < DC; ++j) gc[ct][j] = 0.0f;
+  }
+
+  const long wslice = (long)blockIdx.y * 4 + wave;
+  const long qb0 = wslice * a.bpw;
+  long qb1 = qb0 + a.bpw;
+  qb1 = qb1 < a.nqb ? qb1 : a.nqb;
+  unsigned char* mylds = lds + wave * (2 * BLKB);
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  u4v pre[NP];
+  auto fetch = [&](long qb) {
+    const u4v* src = reinterpret_cast<const u4v*>(a.qblk + (size_t)qb * BLKB);
+#pragma unroll
+    for (int v = 0; v < NP; ++v)
+      if (v * 64 + lane < NV) pre[v] = src[v * 64 + lane];
+  };
+  auto stash = [&](unsigned char* dst) {
+#pragma unroll
+    for (int v = 0; v < NP; ++v)
+      if (v * 64 + lane < NV) reinterpret_cast<u4v*>(dst)[v * 64 + lane] = pre[v];
+  };
+  if (qb0 < qb1) { fetch(qb0); stash(mylds); }
+  wave_sync();
+  for (long qb = qb0; qb < qb1; ++qb) {
+    const unsigned char* cur = mylds + ((qb - qb0) & 1) * BLKB;
+    unsigned char* nxt = mylds + ((qb - qb0 + 1) & 1) * BLKB;
+    const bool has_next = qb + 1 < qb1;
+    if (has_next) fetch(qb + 1);
+    float hq0[CT][4], hq1[CT][4];                             // 2^14 gamma phi of this lane's 8 queries, per tile
+    constexpr int RQ = 4 / CT;                                // queries per inner step: CT * RQ = 4 transcendentals
+    // NOT unrolled: the two halves are independent and hipcc would interleave them (286 VGPRs instead of ~140)
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      // hbar / s_h of the sub-tile's 16 queries x this wave's centres: independent of phi, so it goes first
+      const h4v gah = *reinterpret_cast<const h4v*>(cur + QXB + ((s * 2 + 0) * 64 + lane) * 8);
+      const h4v gal = *reinterpret_cast<const h4v*>(cur + QXB + ((s * 2 + 1) * 64 + lane) * 8);
+      f4v hb[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        hb[ct] = f4v{0, 0, 0, 0};
+        hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wth[ct], hb[ct], 0, 0, 0);
+        hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gal, wth[ct], hb[ct], 0, 0, 0);
+        hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wtl[ct], hb[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r0 = 0; r0 < 4; r0 += RQ) {
+        float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], gm[RQ];
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) {
+          const float* xr = reinterpret_cast<const float*>(cur) + (16 * s + 4 * g + r0 + u) * RFQ;
+          float xv[RFQ];
+#pragma unroll
+          for (int v = 0; v < RFQ / 4; ++v) {
+            const f4v rr = *reinterpret_cast<const f4v*>(xr + 4 * v);
+            xv[4 * v] = rr.x; xv[4 * v + 1] = rr.y; xv[4 * v + 2] = rr.z; xv[4 * v + 3] = rr.w;
+          }
+          gm[u] = xv[RFQ - 1];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+              diff[u][ct][j] = xv[j] - c[ct][j];
+              acc = __builtin_fmaf(diff[u][ct][j], diff[u][ct][j], acc);
+            }
+            r2[u][ct] = acc;
+            t[u * CT + ct] = basis_arg<BC>(acc, sc[ct]);
+          }
+        }
+        trans_block<BC, RQ * CT>(t);                          // phi of the step's 4 pairs
+#pragma unroll
+        for (int u = 0; u < RQ; ++u)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const int r = r0 + u;
+            const float phi = t[u * CT + ct];
+            const float hv = phi * (gm[u] * 16384.0f);
+            if (s == 0) hq0[ct][r] = hv;                      // s is wave-uniform
+            else hq1[ct][r] = hv;
+            const float tt = (hb[ct][r] * sh) * gm[u] * dphi_dd2_h<BC>(phi, a.gscale);   // hbar gamma dphi/dd2
+            gls[ct] = __builtin_fmaf(tt, -2.0f * (r2[u][ct] * s2[ct]), gls[ct]);
+            const float coef = -2.0f * tt * s2[ct];
+#pragma unroll
+            for (int j = 0; j < DC; ++j) gc[ct][j] = __builtin_fmaf(coef, diff[u][ct][j], gc[ct][j]);
+          }
+      }
+    }
+    const h8v gth = *reinterpret_cast<const h8v*>(cur + QXB + 2048 + (0 * 64 + lane) * 16);
+    const h8v gtl = *reinterpret_cast<const h8v*>(cur + QXB + 2048 + (1 * 64 + lane) * 16);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      h8v bh, bl;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float p0 = jj < 2 ? hq0[ct][2 * jj] : hq1[ct][2 * jj - 4];
+        const float p1 = jj < 2 ? hq0[ct][2 * jj + 1] : hq1[ct][2 * jj - 3];
+        const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
+        const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
+        const h2v hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+        const h2v ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
+        bh[2 * jj] = (_Float16)hh[0]; bh[2 * jj + 1] = (_Float16)hh[1];
+        bl[2 * jj] = (_Float16)ll[0]; bl[2 * jj + 1] = (_Float16)ll[1];
+      }
+      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
+      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dW[ct], 0, 0, 0);
+      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dW[ct], 0, 0, 0);
+    }
+    if (has_next) stash(nxt);
+    wave_sync();
+  }
+
+  // ---- this wave's totals: d centers / d log_sigs summed over the 4 lane groups (different queries, same centre)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+      float v = gc[ct][j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      gc[ct][j] = v;
+    }
+    float v = gls[ct];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    gls[ct] = v;
+  }
+  // ---- 4 waves (query slices) summed in fixed order through LDS, slab row written (format of rbf_vjp_kernel)
+  __syncthreads();
+  const int V = DC + 1 + a.OP;
+  constexpr int COLS = 16 * CT;
+  float* red = reinterpret_cast<float*>(lds);                 // [4][V][COLS + 1]
+  const float wscale = sg * 6.103515625e-05f;                 // s_g * 2^-14
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = ct * 16 + n;
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < DC; ++j) red[(wave * V + j) * (COLS + 1) + col] = gc[ct][j];
+      red[(wave * V + DC) * (COLS + 1) + col] = gls[ct];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * g + r;
+      if (o < a.OP) red[(wave * V + DC + 1 + o) * (COLS + 1) + col] = dW[ct][r] * wscale;
+    }
+  }
+  __syncthreads();
+  float* dst = a.part + (size_t)blockIdx.y * V * a.Npad + cb;
+  for (int idx = tid; idx < V * COLS; idx += 256) {
+    const int v = idx / COLS, col = idx - v * COLS;
+    if (cb + col < a.Npad) {
+      const float s = (red[(0 * V + v) * (COLS + 1) + col] + red[(1 * V + v) * (COLS + 1) + col]) +
+                      (red[(2 * V + v) * (COLS + 1) + col] + red[(3 * V + v) * (COLS + 1) + col]);
+      dst[(size_t)v * a.Npad + col] = s;
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+bool vjph_eligible(const irbfn_net* net) {
+  return net->f16_oscale != nullptr && net->R == 1 && net->bclass != BC_GENERIC && net->O <= 16 &&
+         (net->DC == 3 || net->DC == 4 || net->DC == 7 || net->DC == 8);
+}
+
+size_t vjph_block_bytes(const irbfn_net* net) { return (size_t)32 * vjph_rfq(net->DC) * 4 + 4096; }
+
+template <int DC, int CT>
+static int launch_vjph_bc(const VjpHArgs& a, int bc, dim3 grid, size_t lds, hipStream_t s) {
+  switch (bc) {
+    case BC_GAUSS: hipLaunchKernelGGL((rbf_vjp_f16mfma<DC, BC_GAUSS, CT>), grid, dim3(256), lds, s, a); break;
+    case BC_IQ: hipLaunchKernelGGL((rbf_vjp_f16mfma<DC, BC_IQ, CT>), grid, dim3(256), lds, s, a); break;
+    case BC_IMQ: hipLaunchKernelGGL((rbf_vjp_f16mfma<DC, BC_IMQ, CT>), grid, dim3(256), lds, s, a); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int DC>
+static int launch_vjph_dc(const VjpHArgs& a, int CT, int bc, dim3 grid, size_t lds, hipStream_t s) {
+  return CT == 4 ? launch_vjph_bc<DC, 4>(a, bc, grid, lds, s) : launch_vjph_bc<DC, 2>(a, bc, grid, lds, s);
+}
+
+// x, gout -> slabs part[QSB][V][Npad] (QSB query-slice blocks of 4 waves).  qblk / scales: workspace; bmax: per-block
+// max |g| written by colsum_partial_kernel (no separate reduction pass, no atomics).
+int launch_vjp_f16(irbfn_net* net, const float* x, const float* gout, int64_t B, unsigned char* qblk, const float* bmax,
+                   int nbmax, float* scales, float* part, int QSB, int Npad, int CT, hipStream_t s) {
+  if (!vjph_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  const long nqb = (B + 31) / 32;
+  hipLaunchKernelGGL(vjp_pack_blocks_kernel, dim3((unsigned)nqb), dim3(64), 0, s, x, gout, bmax, nbmax, net->f16_oscale,
+                     qblk, scales, net->gate(), (long)B, net->D, vjph_rfq(net->DC), net->O);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  VjpHArgs a;
+  a.qblk = qblk; a.scales = scales; a.rec = net->rec; a.sig2 = net->sig2; a.oscale = net->f16_oscale; a.part = part;
+  a.nqb = nqb; a.O = net->O; a.OP = net->OP; a.N = net->N; a.S = net->S; a.Npad = Npad; a.basis = net->basis;
+  const long slices = (long)QSB * 4;
+  a.bpw = (int)((nqb + slices - 1) / slices);
+  a.gscale = gauss_scale(net->basis);
+  const int groups = (net->N + 16 * CT - 1) / (16 * CT);
+  const dim3 grid(groups, QSB);
+  const int V = net->DC + 1 + net->OP;
+  const size_t ring = (size_t)4 * 2 * vjph_block_bytes(net);
+  const size_t red = (size_t)4 * V * (16 * CT + 1) * sizeof(float);
+  const size_t lds = ring > red ? ring : red;
+  switch (net->DC) {
+    case 3: return launch_vjph_dc<3>(a, CT, net->bclass, grid, lds, s);
+    case 4: return launch_vjph_dc<4>(a, CT, net->bclass, grid, lds, s);
+    case 7: return launch_vjph_dc<7>(a, CT, net->bclass, grid, lds, s);
+    case 8: return launch_vjph_dc<8>(a, CT, net->bclass, grid, lds, s);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace irbfn

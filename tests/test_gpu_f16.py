@@ -172,3 +172,57 @@ def test_f16mfma_wide_outputs(gpu, O, SW):
     # float32-equivalent: the error is that of the shared float32 distance / basis arithmetic
     assert err <= max(2e-6, 2.0 * err_other), (err, err_other)
     assert (np.abs(got - other) / scale).max() <= 1e-5
+
+
+LEAVES = (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias"))
+
+
+@pytest.mark.parametrize("CT", [2, 4])
+@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "imq_d3"])
+def test_vjp_f16mfma_matches_valu_kernel_and_oracle(gpu, case, CT):
+    """K2h (rbf_vjp_f16.hip): hbar and dW on the f16 matrix cores with hi/lo operand splits -- against K2 (all
+    float32 VALU) on the same inputs and against the float64 restatement of the reference's parameter VJP."""
+    import torch
+    rng = np.random.default_rng(11)
+    if case == "cfg3":
+        cfg = dict(configs.model_card(3), num_kernels=500)                 # not a multiple of 32 / 64
+        P = configs.synth_params(3)
+        P = {"params": {"rbf_list": {k: v[:, :500] for k, v in P["params"]["rbf_list"].items()},
+                        "linear": {"kernel": P["params"]["linear"]["kernel"][:500], "bias": P["params"]["linear"]["bias"]}}}
+        B = 4096 + 19
+        x, g = configs.synth_queries(3, B=B), configs.synth_cotangent(3, B=B) * 1e-3
+    elif case == "iq_ckpt":
+        cfg, P, *_ = load_ckpt_fixture("dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq")
+        P = orc.cast_params(P, np.float32)
+        ns = len(cfg["activation_idx"])
+        lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+        B = 3000
+        x = rng.uniform(lo - 0.02, hi + 0.02, size=(B, 7)).astype(np.float32)
+        g = rng.normal(size=(B, 2)).astype(np.float32) * 40.0
+    else:
+        D, K, O = 3, 96, 5
+        cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": "inverse_multiquadric", "num_regions": 1,
+               "lower_bounds": [[-2.0]] * D, "upper_bounds": [[3.0]] * D, "dimension_ranges": [[0] * D],
+               "activation_idx": list(range(D)), "delta": [20.0] * D}
+        P = {"params": {"rbf_list": {"centers": rng.uniform(-3, 4, size=(1, K, D)).astype(np.float32),
+                                     "log_sigs": rng.uniform(-0.5, 1.0, size=(1, K)).astype(np.float32)},
+                        "linear": {"kernel": (rng.normal(size=(K, O)) * np.array([1e-2, 1, 1, 50, 1])).astype(np.float32),
+                                   "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+        B = 2048 + 1
+        x = rng.uniform(-2.2, 3.2, size=(B, D)).astype(np.float32)
+        g = rng.normal(size=(B, O)).astype(np.float32)
+        g[7] = 0.0
+    net = WCRBFNet.from_config(cfg)
+    xt, gt = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    with _env(IRBFN_VJP_F16=1, IRBFN_VJP_F16_CT=CT):
+        a = net.vjp(P, xt, gt)["params"]
+        a2 = net.vjp(P, xt, gt)["params"]
+    with _env(IRBFN_VJP_F16=0):
+        b = net.vjp(P, xt, gt)["params"]
+    ref = orc.wcrbfnet_vjp(cfg, orc.cast_params(P, np.float64), x.astype(np.float64), g.astype(np.float64))["params"]
+    for grp, name in LEAVES:
+        ga, gb, gr = a[grp][name].cpu().numpy(), b[grp][name].cpu().numpy(), np.asarray(ref[grp][name])
+        assert torch.equal(a[grp][name], a2[grp][name])                    # deterministic
+        scale = np.abs(gr).max() + 1e-30
+        ea, eb = np.abs(ga - gr).max() / scale, np.abs(gb - gr).max() / scale
+        assert ea <= max(2e-5, 2.0 * eb), (case, grp, name, ea, eb)
