@@ -148,7 +148,9 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
       int r = j * RPI + rsub;
       r = (r < nvalid && rsub < RPI) ? r : 0;
       const float* g0 = tin + (long)r * a.LU + off;
-      const float* al = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(g0) & ~(uintptr_t)15);
+      // aligned-down pointer by ARITHMETIC on g0 (an integer round trip loses the address space: hipcc then emits
+      // flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) after every single load, which also drains the pending stores)
+      const float* al = g0 - (int)((reinterpret_cast<uintptr_t>(g0) >> 2) & 3);
       v[j] = *reinterpret_cast<const float4*>(al + 4 * part);
     }
 #pragma unroll
@@ -276,6 +278,9 @@ static int dispatch_mode(int mode, const RollArgs& a, hipStream_t s) {
   }
 }
 
+// Measured and rejected: splitting B > 131072 into several launches (hoping the 256 MB memory-side cache would
+// merge the partial lines of one launch): 216 vs 190 us at B = 262144 -- the 71 us seen for a single 131072
+// launch is an artefact of re-running on cache-resident buffers, not a property of the size.
 static int s0_of(int mode) {
   switch (mode) {
     case IRBFN_ROLLOUT_FULLINT: return 1;
