@@ -29,6 +29,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "rbf_forward.h"
 
@@ -578,7 +579,9 @@ int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, in
   const int waves = S * QG;
   const size_t ring = (size_t)waves * 2 * kF16Chunk * f16_rf(net->DC) * 4;
   const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
-  const size_t lds = ring > red ? ring : red;
+  size_t lds = ring > red ? ring : red;
+  if (const char* e = getenv("IRBFN_FWD_F16_LDSPAD")) lds += (size_t)atol(e);   // diagnosis: lowers the occupancy
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   const int grid = (int)((groups + QG - 1) / QG);
   int rc;

@@ -3,13 +3,11 @@ run() { echo "== $1"; shift; env "$@" python bench.py --steps 300 --warmup 30 --
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print(round(j['ms_per_step']*1e3,1), 'us', round(j['roofline']['frac'],3), j['roofline']['kernel'], j['roofline']['grid'], j['roofline']['block'], 'parity', j.get('parity'))
+        j = json.loads(l); print(round(j['ms_per_step']*1e3,1), 'us', round(j['roofline']['frac'],3), j['roofline']['kernel'], j['roofline']['grid'], j['roofline']['block'])
 "; }
-run "K1" A=1
-run "K1h" IRBFN_FWD_F16=1
-run "K1h S4 QG2" IRBFN_FWD_F16=1 IRBFN_FWD_F16_S=4 IRBFN_FWD_F16_QG=2
-run "K1h S8 QG1" IRBFN_FWD_F16=1 IRBFN_FWD_F16_S=8 IRBFN_FWD_F16_QG=1
-run "K1h S4 QG1" IRBFN_FWD_F16=1 IRBFN_FWD_F16_S=4 IRBFN_FWD_F16_QG=1
-run "K1h S2 QG4" IRBFN_FWD_F16=1 IRBFN_FWD_F16_S=2 IRBFN_FWD_F16_QG=4
-run "K1h terms1" IRBFN_FWD_F16=1 IRBFN_FWD_F16_TERMS=1
-run "K1 again" A=1
+run "K1h default" A=1
+run "K1h pad 24K (2 blocks/CU: 4 waves/SIMD)" IRBFN_FWD_F16_LDSPAD=24576
+run "K1h pad 40K (1 block/CU.. 2/SIMD)" IRBFN_FWD_F16_LDSPAD=40960
+run "K1h pad 8K" IRBFN_FWD_F16_LDSPAD=8192
+run "K1h S4 QG1 (256 thr)" IRBFN_FWD_F16_S=4 IRBFN_FWD_F16_QG=1
+run "K1h S2 QG1 (128 thr)" IRBFN_FWD_F16_S=2 IRBFN_FWD_F16_QG=1
