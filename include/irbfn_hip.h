@@ -210,6 +210,16 @@ int irbfn_lut_nearest(const float* inputs_dev, const float* table_dev, const flo
                       float* dist_dev, float* out_dev, int64_t N, int64_t B, int D, int OW, void* ws_dev,
                       int64_t ws_bytes, void* stream);
 
+/* ClusterWCRBFNet (src/irbfn_mpc/model.py:341-414): the region weights are a learned softmax gate instead of the
+ * tanh indicator.  irbfn_cluster_gate: logits = x Wc + bc [B,R] (second output of the reference module) and
+ * gamma = softmax(logits) [B,R]; wc [D,R], bc [R] device pointers.  irbfn_net_forward_gamma: the fused
+ * sum_r gamma[b,r] phi[b,r,k] -> Dense forward (model.py:405-412) with caller-provided gamma_dev [B,R], on a
+ * descriptor created with R regions (its own gate tables are ignored).  Forward only. */
+int irbfn_cluster_gate(const float* x_dev, const float* wc_dev, const float* bc_dev, float* logits_dev, float* gamma_dev,
+                       int64_t B, int D, int R, void* stream);
+int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, float* out_dev, int64_t B,
+                            void* stream);
+
 /* Dense head of DeeperWCRBFNet (src/irbfn_mpc/model.py:201-289; the model of IRBFNFrenetPlanner with
  * deeper=True, src/irbfn_mpc/irbfn_planner.py:286-298):  out = linear(relu(linear_pre2(relu(h1)))) with
  * h1 = linear_pre1(rbf_out) [B,H1] produced by irbfn_net_forward on a descriptor whose Dense layer is

@@ -217,6 +217,23 @@ int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, cons
                                 as_stream(stream));
 }
 
+int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, float* out_dev, int64_t B,
+                            void* stream) {
+  if (!net || B < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || !gamma_dev || !out_dev) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  return launch_forward_gamma(net, x_dev, gamma_dev, out_dev, B, as_stream(stream));
+}
+
+int irbfn_cluster_gate(const float* x_dev, const float* wc_dev, const float* bc_dev, float* logits_dev, float* gamma_dev,
+                       int64_t B, int D, int R, void* stream) {
+  if (B < 0) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!x_dev || !wc_dev || !bc_dev || !logits_dev || !gamma_dev) return IRBFN_ERR_BAD_ARG;
+  return launch_cluster_gate(x_dev, wc_dev, bc_dev, logits_dev, gamma_dev, B, D, R, as_stream(stream));
+}
+
 int irbfn_plan_tick(irbfn_net* net, int mode, const float* x_dev, const int32_t* mirror_dev, const float* state0_dev,
                     const float* dyn_params_host, float* controls_dev, float* states_dev, int64_t B, int T,
                     void* stream) {

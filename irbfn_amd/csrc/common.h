@@ -92,6 +92,9 @@ namespace irbfn {
 int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
                 const float* bias, hipStream_t s);
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
+int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, float* out, int64_t B, hipStream_t s);
+int launch_cluster_gate(const float* x, const float* wc, const float* bc, float* logits, float* gamma, int64_t B, int D,
+                        int R, hipStream_t s);
 bool mfma_eligible(const irbfn_net* net);
 size_t mfma_record_floats(int D, int O);
 int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,

@@ -35,6 +35,10 @@ struct FwdArgs {
   // planner mirror trick (irbfn_planner.py:203-204): rows with mirror[b] != 0 get outputs [sv0, O) negated
   const int* __restrict__ mirror;
   int sv0;
+  // caller-provided region weights gamma[B][R] (ClusterWCRBFNet: softmax gate, model.py:341-414) instead of the
+  // tanh tables; GATED kernels only
+  const float* __restrict__ gamma_ext;
+  int R;
 };
 
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }

@@ -1,5 +1,6 @@
 // K0 (pack), gate kernel and the K1 dispatcher -- see rbf_forward.h for the design of K1; the K1
 // instantiations live in rbf_forward_kernels.hip (one object per compiled D).
+#include <math.h>
 #include "rbf_forward.h"
 
 #include <stdio.h>
@@ -123,7 +124,7 @@ static int pow2_floor(int v) {
 
 static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   const int OP = net->OP;
-  const bool gated = net->R > 1;
+  const bool gated = net->R > 1 || a.gamma_ext != nullptr;
   // --- Q: two queries per lane halve the scalar-stream traffic per pair, but the kernel is VALU-issue
   // bound and more resident waves hide the scalar-load latency better (measured: Q=1,NW=16 152 us vs
   // Q=2,NW=16 175 us at cfg-2), so Q = 2 only once Q = 1 alone over-subscribes the chip.
@@ -189,6 +190,7 @@ static void fill_args(irbfn_net* net, FwdArgs& a, const float* x, float* out, in
   a.K = net->K;
   a.S = net->S;
   a.basis = net->basis;
+  a.R = net->R;
 }
 
 // K1m (Phi x W on the f32 matrix cores).  Opt-in (IRBFN_FWD_MFMA=1): measured on MI355X at cfg-2 it is
@@ -220,6 +222,51 @@ static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t 
   if (nw < 1) nw = 1;
   if (nw > 16) nw = 16;
   return launch_forward_mfma(net, x, out, B, QJ, nw, s);
+}
+
+// ClusterWCRBFNet gate (model.py:402-404): logits = x Wc + bc, gamma = softmax(logits) (max-subtracted, as
+// jax.nn.softmax).  One thread per query, two passes over the R regions; logits are part of the model's output.
+__global__ __launch_bounds__(256) void cluster_gate_kernel(const float* __restrict__ x, const float* __restrict__ wc,
+                                                           const float* __restrict__ bc, float* __restrict__ logits,
+                                                           float* __restrict__ gamma, long B, int D, int R) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float xv[16];
+  for (int d = 0; d < D; ++d) xv[d] = x[b * D + d];
+  float mx = -INFINITY;
+  for (int r = 0; r < R; ++r) {
+    float l = bc[r];
+    for (int d = 0; d < D; ++d) l = __builtin_fmaf(xv[d], wc[d * R + r], l);
+    logits[b * R + r] = l;
+    mx = fmaxf(mx, l);
+  }
+  float sum = 0.0f;
+  for (int r = 0; r < R; ++r) {
+    const float e = expf(logits[b * R + r] - mx);
+    gamma[b * R + r] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / sum;
+  for (int r = 0; r < R; ++r) gamma[b * R + r] *= inv;
+}
+
+int launch_cluster_gate(const float* x, const float* wc, const float* bc, float* logits, float* gamma, int64_t B, int D,
+                        int R, hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  if (D < 1 || D > 16 || R < 1) return IRBFN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cluster_gate_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, x, wc, bc, logits, gamma,
+                     (long)B, D, R);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// forward with caller-provided region weights gamma[B][R] (ClusterWCRBFNet): always the gated K1
+int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, float* out, int64_t B, hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  FwdArgs a;
+  fill_args(net, a, x, out, B);
+  a.gamma_ext = gamma;
+  return run_forward(net, a, false, s);
 }
 
 // K1h (Phi x W on the f16 matrix cores at float32 accuracy, rbf_forward_f16.hip): narrow outputs, one region.

@@ -192,7 +192,11 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         float g = 0.0f;
-        if (r < gt.n_ranges) {                   // model.py:88-93
+        if (a.gamma_ext != nullptr) {            // external gate (ClusterWCRBFNet softmax, model.py:402-408)
+          int rr = lane + kWave * q;
+          rr = rr < nvalid ? rr : nvalid - 1;
+          g = a.gamma_ext[(row0 + rr) * a.R + r];
+        } else if (r < gt.n_ranges) {            // model.py:88-93
           g = 1.0f;
           for (int d = 0; d < gt.nsplit; ++d) {
             const int e = d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d];

@@ -335,6 +335,44 @@ class DeeperWCRBFNet:
         return like_input(out, x, torch)
 
 
+class ClusterWCRBFNet:
+    """``ClusterWCRBFNet`` of the reference (src/irbfn_mpc/model.py:341-414): R RBF layers mixed by a learned
+    softmax gate ``softmax(Dense(R)(x))`` instead of the tanh indicator.  Parameter pytree: ``{"rbf_list":
+    {centers[R,K,D], log_sigs[R,K]}, "linear": {kernel[K,O], bias[O]}, "cluster": {kernel[D,R], bias[R]}}``.
+    ``apply`` returns ``(out, logits)`` like the reference module.  Forward only; no trained checkpoint of this
+    variant survives in the reference (.MISSING_LARGE_BLOBS) -> parity against the oracle restatement only."""
+
+    def __init__(self, in_features, out_features, num_kernels, basis_func, num_regions, **_unused):
+        self.in_features, self.out_features = int(in_features), int(out_features)
+        self.num_regions = int(num_regions)
+        # descriptor with R regions and no gate tables: the region weights come from the softmax gate
+        self.stage = WCRBFNet(in_features=in_features, out_features=out_features, num_kernels=num_kernels,
+                              basis_func=basis_func, num_regions=num_regions, lower_bounds=[], upper_bounds=[],
+                              dimension_ranges=[], activation_idx=[], delta=[])
+
+    def apply(self, params: dict, x):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        D, R, O = self.in_features, self.num_regions, self.out_features
+        if tuple(p["cluster"]["kernel"].shape) != (D, R) or tuple(p["cluster"]["bias"].shape) != (R,):
+            raise ValueError(f"params cluster.kernel / bias must be [{D},{R}] / [{R}]")
+        self.stage.bind({"rbf_list": p["rbf_list"], "linear": p["linear"]})
+        xd = to_device_f32(x, torch)
+        B = xd.shape[0]
+        if tuple(xd.shape) != (B, D):
+            raise ValueError(f"x must be [B, {D}]")
+        wc, bc = to_device_f32(p["cluster"]["kernel"], torch), to_device_f32(p["cluster"]["bias"], torch)
+        logits = torch.empty((B, R), dtype=torch.float32, device=xd.device)
+        gamma = torch.empty((B, R), dtype=torch.float32, device=xd.device)
+        out = torch.empty((B, O), dtype=torch.float32, device=xd.device)
+        st = lib.irbfn_cluster_gate(_ptr(xd), _ptr(wc), _ptr(bc), _ptr(logits), _ptr(gamma), B, D, R, _stream_ptr(torch))
+        _lib.check(st, "irbfn_cluster_gate")
+        st = lib.irbfn_net_forward_gamma(self.stage._handle(torch), _ptr(xd), _ptr(gamma), _ptr(out), B, _stream_ptr(torch))
+        _lib.check(st, "irbfn_net_forward_gamma")
+        return like_input(out, x, torch), like_input(logits, x, torch)
+
+
 class _State:
     """Minimal stand-in of flax's TrainState for ``pred_step``: ``apply_fn`` + ``params``."""
 

@@ -273,6 +273,23 @@ def deeper_wcrbfnet_apply(cfg: dict, params: dict, x):
     return relu(out_pre2) @ p["linear"]["kernel"] + p["linear"]["bias"]                 # :285
 
 
+def cluster_wcrbfnet_apply(cfg: dict, params: dict, x):
+    """ClusterWCRBFNet.__call__ -- src/irbfn_mpc/model.py:393-414: (out, logits)."""
+    p = params["params"] if "params" in params else params
+    x = np.asarray(x, np.float64)
+    c = np.asarray(p["rbf_list"]["centers"], np.float64)            # [R,K,D]
+    ls = np.asarray(p["rbf_list"]["log_sigs"], np.float64)          # [R,K]
+    basis = BASIS[cfg["basis_func"]]
+    d = np.sqrt(((x[:, None, None, :] - c[None]) ** 2).sum(-1)) / np.exp(ls)[None]     # flax_rbf.py:280
+    all_x = basis(d, np)                                            # [B,R,K]                    model.py:400
+    logits = x @ np.asarray(p["cluster"]["kernel"], np.float64) + np.asarray(p["cluster"]["bias"], np.float64)   # :403
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    cluster_ind = e / e.sum(axis=1, keepdims=True)                  # nn.softmax                 :404
+    rbf_out = (cluster_ind[:, :, None] * all_x).sum(axis=1)         # :405-409
+    out = rbf_out @ np.asarray(p["linear"]["kernel"], np.float64) + np.asarray(p["linear"]["bias"], np.float64)  # :412
+    return out, logits
+
+
 def wcrbfnet_vjp(cfg: dict, params: dict, x: np.ndarray, gout: np.ndarray):
     """Hand-derived VJP of a-4 w.r.t. the parameters, float64 NumPy.
     Only for bases that depend on d^2 alone (gaussian*, inverse_quadratic,

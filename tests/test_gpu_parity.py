@@ -555,3 +555,30 @@ def test_deeper_wcrbfnet_forward(gpu, B):
     bad = {"params": dict(params["params"], linear_pre2={"kernel": np.zeros((64, 32)), "bias": np.zeros(32)})}
     with pytest.raises(ValueError):
         net.apply(bad, xs.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,O,B", [(11, 20, 10, 500), (2, 64, 2, 70), (1, 33, 5, 130), (64, 8, 10, 3000)])
+def test_cluster_wcrbfnet_forward(gpu, R, K, O, B):
+    """ClusterWCRBFNet (model.py:341-414): softmax gate kernel + fused forward with external region
+    weights, against the float64 restatement.  No trained checkpoint of this variant survives in the reference."""
+    from irbfn_amd.model import ClusterWCRBFNet
+    rng = np.random.default_rng(R * 7 + K)
+    D = 8
+    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": "gaussian", "num_regions": R}
+    params = {"params": {
+        "rbf_list": {"centers": rng.uniform(-2, 2, size=(R, K, D)).astype(np.float32),
+                     "log_sigs": rng.uniform(0.0, 1.0, size=(R, K)).astype(np.float32)},
+        "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)},
+        "cluster": {"kernel": rng.normal(size=(D, R)).astype(np.float32) * 2.0, "bias": rng.normal(size=(R,)).astype(np.float32)}}}
+    x = rng.uniform(-2, 2, size=(B, D)).astype(np.float32)
+    net = ClusterWCRBFNet(**cfg)
+    out, logits = net.apply(params, x)
+    p64 = {"params": {k: {n: np.asarray(v, np.float64) for n, v in d.items()} for k, d in params["params"].items()}}
+    ref_out, ref_logits = orc.cluster_wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    assert out.shape == (B, O) and logits.shape == (B, R)
+    assert np.abs(logits - ref_logits).max() <= 1e-5 * (1 + np.abs(ref_logits).max())
+    assert np.abs(out - ref_out).max() <= 2e-5 * np.abs(ref_out).max() + 1e-5
+    bad = {"params": dict(params["params"], cluster={"kernel": np.zeros((D, R + 1), np.float32), "bias": np.zeros(R + 1, np.float32)})}
+    with pytest.raises(ValueError):
+        net.apply(bad, x)
