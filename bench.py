@@ -153,8 +153,7 @@ def main():
         "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
         "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
-        "note": "fp32 kernel: peak = 157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak); the kernel "
-                "is VALU/transcendental-bound (2400 flop/B), not HBM-bound; transcendental count = B*N",
+        "note": "priced against the fp32 peak 157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak): distances, basis and the operand splits run on the f32 VALU, the centre x weight reduction on the f16 matrix cores with hi/lo operand pairs (float32-equivalent result, same error as the all-f32 kernel); VALU/transcendental-bound (2400 flop/B), not HBM-bound; transcendental count = B*N",
         "hbm": {"achieved": abytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": abytes / kern_s / 1e9 / PEAK_HBM_GBS},
     }
