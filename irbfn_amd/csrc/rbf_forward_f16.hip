@@ -392,16 +392,26 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
           ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
           al[t][2 * jj] = (_Float16)ll[0]; al[t][2 * jj + 1] = (_Float16)ll[1];
         }
+      // W operands of tile ct + 1 are read while the 6 MFMAs of tile ct run (the LDS latency is otherwise
+      // exposed 7 times per step: hipcc issues each read right in front of its first use)
+      h8_t bh = *reinterpret_cast<const h8_t*>(cur + RECB + lane * 16);
+      h8_t bl = *reinterpret_cast<const h8_t*>(cur + RECB + kF16WBytes + lane * 16);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
-        const h8_t bh = *reinterpret_cast<const h8_t*>(cur + RECB + ct * 2 * kF16WBytes + lane * 16);
-        const h8_t bl = *reinterpret_cast<const h8_t*>(cur + RECB + ct * 2 * kF16WBytes + kF16WBytes + lane * 16);
+        h8_t nbh = bh, nbl = bl;
+        if (ct + 1 < NT) {
+          nbh = *reinterpret_cast<const h8_t*>(cur + RECB + (ct + 1) * 2 * kF16WBytes + lane * 16);
+          nbl = *reinterpret_cast<const h8_t*>(cur + RECB + (ct + 1) * 2 * kF16WBytes + kF16WBytes + lane * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][ct], 0, 0, 0);
           acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][ct], 0, 0, 0);
           acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][ct], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        bh = nbh; bl = nbl;
       }
     }
     if (has_next) stash(nxt);
