@@ -176,7 +176,8 @@ def main():
         ref64 = co.wcrbf_forward(card, params_np(params), xs[:1024], np.float64)
         cpu = {"value": ns / dt, "unit": "evals/s", "cores": co.num_threads(), "kind": "port",
                "sample": f"{ns} of the {B} queries of the same workload x 5 repeats (median), float32, OpenMP C "
-                         f"restatement of the reference path (oracle/irbfn_oracle.c), {dt:.3f} s wall per repeat",
+                         f"restatement of the reference path (oracle/irbfn_oracle.c), {dt:.3f} s wall per repeat "
+                         f"(~{5 * dt * co.num_threads():.0f} core-seconds of CPU work in total)",
                "parity_rel_err_vs_f64": float(np.abs(got[:1024] - ref64).max() / np.abs(ref64).max()),
                "parity_rel_err_vs_cpu_f32": float(np.abs(got - ref).max() / np.abs(ref).max())}
 
