@@ -1,7 +1,7 @@
 // K2h: parameter VJP of the single-region RBF net with its two GEMM-shaped pieces on the f16 matrix cores at
 // float32 accuracy (same hi/lo operand split as the forward kernel K1h, rbf_forward_f16.hip):
 //     hbar[q,k] = sum_o g[q,o] W[k,o]        (v_mfma_f32_16x16x16_f16: rows = queries, cols = centres, k = outputs)
-//     dW[k,o]   = sum_q gamma_q phi[q,k] g[q,o]   (v_mfma_f32_16x16x32_f16: rows = outputs, cols = centres, k = queries)
+//     dW[k,o]   = sum_q gamma_q phi[q,k] g[q,o]   (v_mfma_f32_16x16x16_f16: rows = outputs, cols = centres, k = queries)
 // and everything else (distances, basis, d centers, d log_sigs; SURVEY App. A.2, jax.value_and_grad at
 // scripts/train_nmpc.py:297-298) on the VALU.  Replaces rbf_vjp_kernel (K2) where eligible and writes the
 // same slab format, so vjp_reduce_kernel and the bias column sums are shared.
@@ -11,7 +11,8 @@
 // per query block, the 8 queries qid_g(p) = 16 (p >> 2) + 4 g + (p & 3): exactly the rows the 16x16x16 MFMA
 // returns to this lane (hbar needs no transpose) and, read as k = 8 g + p, a valid B operand of the dW MFMA.
 // Query blocks come pre-packed (vjp_pack_blocks_kernel): x and gamma as float rows for broadcast LDS reads,
-// g as ready-made f16 (hi, lo) MFMA operands in both orientations.
+// g as ready-made f16 (hi, lo) MFMA operands in both orientations.  Both MFMAs are issued per 16-query half:
+// its 4 queries per lane are the k-slice 4 g + j of the 16x16x16 dW product as well.
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
     row[RFQ - 1] = gm;
   }
   h4v* gA = reinterpret_cast<h4v*>(p + 32 * RFQ * 4);                // [s][part][lane] x 4 halfs
-  h8v* gT = reinterpret_cast<h8v*>(p + 32 * RFQ * 4 + 2048);         // [part][lane] x 8 halfs
   // A operand of the hbar MFMA: rows = queries 16 s + n, k = outputs 4 g + j, scaled by s_o / s_h
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -94,19 +94,24 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
     gA[(s * 2 + 0) * 64 + lane] = hi;
     gA[(s * 2 + 1) * 64 + lane] = lo;
   }
-  // A operand of the dW MFMA: rows = outputs n, k = 8 g + j <-> query qid_g(j), scaled by 1 / s_g
-  h8v thi, tlo;
+  // A operand of the dW MFMA (16x16x16, one per 16-query half): rows = outputs n, k = 4 g + j <-> query 16 s + 4 g + j
+  // (the lane's own 4 queries of that half), scaled by 1 / s_g
+  h4v* gT = reinterpret_cast<h4v*>(p + 32 * RFQ * 4 + 2048);         // [s][part][lane] x 4 halfs
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const long q = q0 + 16 * (j >> 2) + 4 * g + (j & 3);
-    float v = 0.0f;
-    if (q < B && n < O) v = gout[q * O + n] / sg;
-    const _Float16 h = (_Float16)v;
-    thi[j] = h;
-    tlo[j] = (_Float16)(v - (float)h);
+  for (int s = 0; s < 2; ++s) {
+    h4v hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long q = q0 + 16 * s + 4 * g + j;
+      float v = 0.0f;
+      if (q < B && n < O) v = gout[q * O + n] / sg;
+      const _Float16 h = (_Float16)v;
+      hi[j] = h;
+      lo[j] = (_Float16)(v - (float)h);
+    }
+    gT[(s * 2 + 0) * 64 + lane] = hi;
+    gT[(s * 2 + 1) * 64 + lane] = lo;
   }
-  gT[0 * 64 + lane] = thi;
-  gT[1 * 64 + lane] = tlo;
 }
 
 // ---- main kernel -------------------------------------------------------------------------------------------
@@ -135,8 +140,10 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
   const int g = lane >> 4, n = lane & 15;
   const int cb = blockIdx.x * 16 * CT;
   const float sg = a.scales[0], sh = a.scales[1];
+  // s_h times the constant of dphi/dd2 (gaussian family: -a; inverse quadratic: -1; inverse multiquadric: -1/2)
+  const float shk = sh * (BC == BC_GAUSS ? -a.gscale : (BC == BC_IQ ? -1.0f : -0.5f));
 
-  float c[CT][DC], sc[CT], s2[CT];
+  float c[CT][DC], sc[CT], s2m2[CT];
   h4v wth[CT], wtl[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
 #pragma unroll
     for (int j = 0; j < DC; ++j) c[ct][j] = rp[j];
     sc[ct] = rp[DC];
-    s2[ct] = a.sig2[cid];
+    s2m2[ct] = -2.0f * a.sig2[cid];                          // -2 / sigma^2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int o = 4 * g + j;
@@ -195,12 +202,11 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
     unsigned char* nxt = mylds + ((qb - qb0 + 1) & 1) * BLKB;
     const bool has_next = qb + 1 < qb1;
     if (has_next) fetch(qb + 1);
-    float hq0[CT][4], hq1[CT][4];                             // 2^14 gamma phi of this lane's 8 queries, per tile
     constexpr int RQ = 4 / CT;                                // queries per inner step: CT * RQ = 4 transcendentals
     // NOT unrolled: the two halves are independent and hipcc would interleave them (286 VGPRs instead of ~140)
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-      // hbar / s_h of the sub-tile's 16 queries x this wave's centres: independent of phi, so it goes first
+      // hbar / s_h of the half's 16 queries x this wave's centres: independent of phi, so it goes first
       const h4v gah = *reinterpret_cast<const h4v*>(cur + QXB + ((s * 2 + 0) * 64 + lane) * 8);
       const h4v gal = *reinterpret_cast<const h4v*>(cur + QXB + ((s * 2 + 1) * 64 + lane) * 8);
       f4v hb[CT];
@@ -211,9 +217,10 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
         hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gal, wth[ct], hb[ct], 0, 0, 0);
         hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wtl[ct], hb[ct], 0, 0, 0);
       }
+      float hq[CT][4];                                        // 2^14 gamma phi of this lane's 4 queries of the half
 #pragma unroll
       for (int r0 = 0; r0 < 4; r0 += RQ) {
-        float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], gm[RQ];
+        float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], gm16[RQ], kq[RQ];
 #pragma unroll
         for (int u = 0; u < RQ; ++u) {
           const float* xr = reinterpret_cast<const float*>(cur) + (16 * s + 4 * g + r0 + u) * RFQ;
@@ -223,7 +230,8 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
             const f4v rr = *reinterpret_cast<const f4v*>(xr + 4 * v);
             xv[4 * v] = rr.x; xv[4 * v + 1] = rr.y; xv[4 * v + 2] = rr.z; xv[4 * v + 3] = rr.w;
           }
-          gm[u] = xv[RFQ - 1];
+          gm16[u] = xv[RFQ - 1] * 16384.0f;
+          kq[u] = xv[RFQ - 1] * shk;                          // gamma * s_h * (basis constant of dphi/dd2)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             float acc = 0.0f;
@@ -243,36 +251,38 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
           for (int ct = 0; ct < CT; ++ct) {
             const int r = r0 + u;
             const float phi = t[u * CT + ct];
-            const float hv = phi * (gm[u] * 16384.0f);
-            if (s == 0) hq0[ct][r] = hv;                      // s is wave-uniform
-            else hq1[ct][r] = hv;
-            const float tt = (hb[ct][r] * sh) * gm[u] * dphi_dd2_h<BC>(phi, a.gscale);   // hbar gamma dphi/dd2
-            gls[ct] = __builtin_fmaf(tt, -2.0f * (r2[u][ct] * s2[ct]), gls[ct]);
-            const float coef = -2.0f * tt * s2[ct];
+            hq[ct][r] = phi * gm16[u];
+            // tt = hbar * gamma * dphi/dd2:  gaussian -a phi | IQ -phi^2 | IMQ -phi^3 / 2  (constants folded into kq)
+            float pw = phi;
+            if constexpr (BC == BC_IQ) pw = phi * phi;
+            if constexpr (BC == BC_IMQ) pw = phi * phi * phi;
+            const float tt = hb[ct][r] * kq[u] * pw;
+            gls[ct] = __builtin_fmaf(tt, r2[u][ct] * s2m2[ct], gls[ct]);      // tt * (-2 d2)
+            const float coef = tt * s2m2[ct];                                  // -2 tt / sigma^2
 #pragma unroll
             for (int j = 0; j < DC; ++j) gc[ct][j] = __builtin_fmaf(coef, diff[u][ct][j], gc[ct][j]);
           }
       }
-    }
-    const h8v gth = *reinterpret_cast<const h8v*>(cur + QXB + 2048 + (0 * 64 + lane) * 16);
-    const h8v gtl = *reinterpret_cast<const h8v*>(cur + QXB + 2048 + (1 * 64 + lane) * 16);
+      // dW of the half: rows = outputs, cols = centres, k = the lane's 4 queries
+      const h4v gth = *reinterpret_cast<const h4v*>(cur + QXB + 2048 + ((s * 2 + 0) * 64 + lane) * 8);
+      const h4v gtl = *reinterpret_cast<const h4v*>(cur + QXB + 2048 + ((s * 2 + 1) * 64 + lane) * 8);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      h8v bh, bl;
+      for (int ct = 0; ct < CT; ++ct) {
+        h4v bh, bl;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float p0 = jj < 2 ? hq0[ct][2 * jj] : hq1[ct][2 * jj - 4];
-        const float p1 = jj < 2 ? hq0[ct][2 * jj + 1] : hq1[ct][2 * jj - 3];
-        const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
-        const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
-        const h2v hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
-        const h2v ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
-        bh[2 * jj] = (_Float16)hh[0]; bh[2 * jj + 1] = (_Float16)hh[1];
-        bl[2 * jj] = (_Float16)ll[0]; bl[2 * jj + 1] = (_Float16)ll[1];
+        for (int jj = 0; jj < 2; ++jj) {
+          const float p0 = hq[ct][2 * jj], p1 = hq[ct][2 * jj + 1];
+          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
+          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
+          const h2v hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+          const h2v ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
+          bh[2 * jj] = (_Float16)hh[0]; bh[2 * jj + 1] = (_Float16)hh[1];
+          bl[2 * jj] = (_Float16)ll[0]; bl[2 * jj + 1] = (_Float16)ll[1];
+        }
+        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bh, dW[ct], 0, 0, 0);
+        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gtl, bh, dW[ct], 0, 0, 0);
+        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bl, dW[ct], 0, 0, 0);
       }
-      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
-      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dW[ct], 0, 0, 0);
-      dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dW[ct], 0, 0, 0);
     }
     if (has_next) stash(nxt);
     wave_sync();
