@@ -276,7 +276,7 @@ int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, flo
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (!net->f16_img) return IRBFN_ERR_UNSUPPORTED;
   const int e = env_int("IRBFN_FWD_F16", IRBFN_F16_DEFAULT);
-  if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 2048)) return IRBFN_ERR_UNSUPPORTED;
+  if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 65)) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   if (net->O > 16) {
     // wide outputs: block-shared W stream; SW = centre slices per block so that the grid covers the 256 CUs

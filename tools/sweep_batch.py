@@ -14,7 +14,7 @@ card = configs.model_card(idx)
 net = WCRBFNet.from_config(card)
 net.bind(distributed.params_to_device(configs.synth_params(idx)))
 N = card["num_kernels"]
-for B in (1, 16, 64, 256, 1024, 4096, 16384, 65536, 262144, 1048576):
+for B in (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 16384, 65536, 262144, 1048576):
     x = torch.from_numpy(configs.synth_queries(idx, B=B)).cuda()
     net(x)
     torch.cuda.synchronize()
