@@ -283,7 +283,9 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
     int SW = 1;
     while (SW < 4 && (groups * SW + 7) / 8 < 256) SW *= 2;
     SW = env_int("IRBFN_FWD_F16_S", SW);
-    return launch_forward_f16(net, x, out, B, SW, 8 / (SW < 1 ? 1 : SW), 3, s);
+    if (SW != 1 && SW != 2 && SW != 4) SW = 1;
+    const int QGw = env_int("IRBFN_FWD_F16_QG", 8 / SW);
+    return launch_forward_f16(net, x, out, B, SW, QGw, 3, s);
   }
   long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
   int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);

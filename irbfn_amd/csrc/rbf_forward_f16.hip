@@ -490,7 +490,7 @@ int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs,
 }
 
 template <int DC, int NT>
-static int launch_f16w_bc(const F16Args& a, int bc, int grid, size_t lds, hipStream_t s) {
+static int launch_f16w_bc(const F16Args& a, int bc, int grid, int block, size_t lds, hipStream_t s) {
 #define IRBFN_WCASE(BCV)                                                                                      \
   case BCV: {                                                                                                 \
     auto k = rbf_fwd_f16mfma_wide<DC, BCV, NT>;                                                               \
@@ -499,7 +499,7 @@ static int launch_f16w_bc(const F16Args& a, int bc, int grid, size_t lds, hipStr
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
       if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }                               \
     }                                                                                                         \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                  \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, s, a);                                                \
     break;                                                                                                    \
   }
   switch (bc) {
@@ -514,48 +514,48 @@ static int launch_f16w_bc(const F16Args& a, int bc, int grid, size_t lds, hipStr
 }
 
 template <int DC>
-static int launch_f16w_dc(const F16Args& a, int NT, int bc, int grid, size_t lds, hipStream_t s) {
+static int launch_f16w_dc(const F16Args& a, int NT, int bc, int grid, int block, size_t lds, hipStream_t s) {
   switch (NT) {
-    case 2: return launch_f16w_bc<DC, 2>(a, bc, grid, lds, s);
-    case 3: return launch_f16w_bc<DC, 3>(a, bc, grid, lds, s);
-    case 4: return launch_f16w_bc<DC, 4>(a, bc, grid, lds, s);
-    case 5: return launch_f16w_bc<DC, 5>(a, bc, grid, lds, s);
-    case 6: return launch_f16w_bc<DC, 6>(a, bc, grid, lds, s);
-    case 7: return launch_f16w_bc<DC, 7>(a, bc, grid, lds, s);
-    case 8: return launch_f16w_bc<DC, 8>(a, bc, grid, lds, s);
+    case 2: return launch_f16w_bc<DC, 2>(a, bc, grid, block, lds, s);
+    case 3: return launch_f16w_bc<DC, 3>(a, bc, grid, block, lds, s);
+    case 4: return launch_f16w_bc<DC, 4>(a, bc, grid, block, lds, s);
+    case 5: return launch_f16w_bc<DC, 5>(a, bc, grid, block, lds, s);
+    case 6: return launch_f16w_bc<DC, 6>(a, bc, grid, block, lds, s);
+    case 7: return launch_f16w_bc<DC, 7>(a, bc, grid, block, lds, s);
+    case 8: return launch_f16w_bc<DC, 8>(a, bc, grid, block, lds, s);
     default: return IRBFN_ERR_UNSUPPORTED;
   }
 }
 
 // SW centre slices (1, 2 or 4) x QG = 8 / SW query groups of 32 per 512-thread block
-static int launch_forward_f16_wide(irbfn_net* net, const float* x, float* out, int64_t B, int SW, hipStream_t s) {
+static int launch_forward_f16_wide(irbfn_net* net, const float* x, float* out, int64_t B, int SW, int QG, hipStream_t s) {
   const int NT = f16_nt(net);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   if (SW != 1 && SW != 2 && SW != 4) return IRBFN_ERR_BAD_ARG;
   while (SW > 1 && nchunks / SW < 2) SW /= 2;
-  const int QG = 8 / SW;
+  if (QG < 2 || SW * QG > 8) QG = 8 / SW;                    // the copy team needs >= 128 threads per slice
   F16Args a;
   a.x = x; a.img = net->f16_img; a.oscale = net->f16_oscale; a.bias = net->bias; a.out = out; a.gate = net->gate();
   a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.nchunks = nchunks; a.S = SW; a.QG = QG;
   const size_t stream = (size_t)SW * 2 * f16_chunk_bytes(net->DC, NT);
-  const size_t red = ((size_t)8 * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
+  const size_t red = ((size_t)SW * QG * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
   const size_t lds = stream > red ? stream : red;
   if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   const int grid = (int)((groups + QG - 1) / QG);
   int rc;
   switch (net->DC) {
-    case 3: rc = launch_f16w_dc<3>(a, NT, net->bclass, grid, lds, s); break;
-    case 4: rc = launch_f16w_dc<4>(a, NT, net->bclass, grid, lds, s); break;
-    case 7: rc = launch_f16w_dc<7>(a, NT, net->bclass, grid, lds, s); break;
-    case 8: rc = launch_f16w_dc<8>(a, NT, net->bclass, grid, lds, s); break;
+    case 3: rc = launch_f16w_dc<3>(a, NT, net->bclass, grid, SW * QG * 64, lds, s); break;
+    case 4: rc = launch_f16w_dc<4>(a, NT, net->bclass, grid, SW * QG * 64, lds, s); break;
+    case 7: rc = launch_f16w_dc<7>(a, NT, net->bclass, grid, SW * QG * 64, lds, s); break;
+    case 8: rc = launch_f16w_dc<8>(a, NT, net->bclass, grid, SW * QG * 64, lds, s); break;
     default: rc = IRBFN_ERR_UNSUPPORTED;
   }
   if (rc == IRBFN_OK) {
     snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16mfma_wide<D=%d,BC=%d,NT=%d,SW=%d,QG=%d>", net->DC,
              net->bclass, NT, SW, QG);
     net->last_grid = grid;
-    net->last_block = 512;
+    net->last_block = SW * QG * 64;
   }
   return rc;
 }
@@ -580,7 +580,7 @@ static int launch_f16_dc(const F16Args& a, int terms, int bc, int grid, int bloc
 // S = centre slices per query group, QG = query groups (of 32) per block; S * QG <= 8 waves
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s) {
   if (!net->f16_img || !f16_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
-  if (net->O > 16) return launch_forward_f16_wide(net, x, out, B, S, s);
+  if (net->O > 16) return launch_forward_f16_wide(net, x, out, B, S, QG, s);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   if (S < 1 || QG < 1 || S * QG > 8 || S > nchunks) return IRBFN_ERR_BAD_ARG;
   F16Args a;
