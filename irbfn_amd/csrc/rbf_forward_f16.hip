@@ -222,22 +222,24 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
     }
     trans_block<BC, 16>(t16);                                // phi' = 2^14 * phi for the step's 16 pairs
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      u4_t wh, wl;                                           // 4 packed f16 pairs each = one MFMA A operand
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const float p0 = t16[t * 8 + 2 * jj], p1 = t16[t * 8 + 2 * jj + 1];
         if constexpr (TERMS >= 2) {
           const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
           const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
-          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
-          const h2_t ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
-          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
-          al[t][2 * jj] = (_Float16)ll[0]; al[t][2 * jj + 1] = (_Float16)ll[1];
+          wh[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+          wl[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
         } else {
-          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
+          wh[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+          wl[jj] = 0u;
         }
       }
+      ah[t] = __builtin_bit_cast(h8_t, wh);
+      al[t] = __builtin_bit_cast(h8_t, wl);
+    }
     bh = nbh; bl = nbl;
     if (has_next) store_rec(nxt, pre);
     wave_sync();
