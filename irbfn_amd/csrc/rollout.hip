@@ -255,6 +255,172 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
   }
 }
 
+// K3b: the same roll-out with a ROLLED step loop.  The 32-step unroll of rollout_fwd_kernel keeps 64 control
+// values in VGPRs (239 VGPRs -> 2 waves per SIMD), which leaves the LDS-read -> store latency of every flush
+// exposed.  Here a group of 4 steps is the unit: the group's controls (2 streams x 4 values per row) are staged
+// through the SAME tile that stages the group's output states (aligned 16-byte pieces fetched one group ahead
+// into 4 VGPRs per lane), so a wave needs ~90 VGPRs and one 9.5 KB tile: 4 waves per SIMD.
+template <int MODE>
+__global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(const RollArgs a) {
+  extern __shared__ float lds[];
+  constexpr int S = ModeTraits<MODE>::S;
+  constexpr int TS = kRollTS;
+  constexpr int CF = TS * S;
+  constexpr int NP = CF / 4;
+  constexpr int PITCH = 37;
+  static_assert(CF % 4 == 0 && CF + 3 <= PITCH && NP <= 8 && TS == 4, "lean roll-out: 4-step groups");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long b0 = ((long)blockIdx.x * kRollWaves + wave) * kWave;
+  if (b0 >= a.B) return;
+  const long left = a.B - b0;
+  const int nvalid = left < kWave ? (int)left : kWave;
+  const bool last_tile = left <= kWave;
+  const int T = a.T;
+  const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
+  const float* row = a.x0 + bb * a.L0;
+  const float* urow = a.u + bb * a.LU;
+  float* tile = lds + wave * (kWave * PITCH);
+  float* mine = tile + lane * PITCH;
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  float* gout = a.states + b0 * (long)T * S;
+  auto carry_of = [&](int r) { return (int)((reinterpret_cast<uintptr_t>(gout + (long)r * T * S) >> 2) & 3); };
+  const int myC = carry_of(lane < nvalid ? lane : 0);
+
+  float s[S];
+  [[maybe_unused]] float coef[4];
+  [[maybe_unused]] float slen = 0.0f;
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
+    s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
+    s[3] = clipf(row[0], 0.0f, 7.0f);
+  } else if constexpr (MODE == IRBFN_ROLLOUT_SPIRAL) {
+    float q[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] = row[i];
+    spiral_coefs(q, coef);
+    slen = q[4];
+    s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[3] = coef[0]; s[4] = 0.0f; s[5] = 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < S; ++i) s[i] = row[i];
+  }
+
+  // control pieces: per row 2 streams x 2 aligned float4 (the 4 wanted floats lie inside 8 aligned ones);
+  // lane l covers rows l/4 + 16 j (j < 4), stream (l >> 1) & 1, half l & 1
+  const int crow = lane >> 2, cstream = (lane >> 1) & 1, chalf = lane & 1;
+  float4 pre[4];
+  auto fetch_ctrl = [&](int t0) {                // controls of steps [t0, t0 + 4) of every row -> pre
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int r = crow + 16 * j;
+      r = r < nvalid ? r : nvalid - 1;
+      const float* g0 = a.u + (b0 + r) * a.LU + (cstream ? T : 0) + t0;
+      const float* al = g0 - (int)((reinterpret_cast<uintptr_t>(g0) >> 2) & 3);
+      pre[j] = *reinterpret_cast<const float4*>(al + 4 * chalf);
+    }
+  };
+  auto stash_ctrl = [&]() {                      // pre -> tile[row][stream * 8 + 4 half ..]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = crow + 16 * j;
+      float* t = tile + r * PITCH + 3 + cstream * 8 + 4 * chalf;       // [0, 3) stays free for the carry
+      t[0] = pre[j].x; t[1] = pre[j].y; t[2] = pre[j].z; t[3] = pre[j].w;
+    }
+  };
+  auto flush = [&](int t0, bool first) {
+    const int rsub = lane >> 3, part = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = j * 8 + rsub;
+      if (r < nvalid && part < NP) {
+        const int C = carry_of(r);
+        const float* src = tile + r * PITCH + 4 * part;
+        float* dst = gout + (long)r * T * S + (long)t0 * S - C + 4 * part;
+        if (first && part == 0 && C > 0) {
+          for (int i = C; i < 4; ++i) dst[i] = src[i];
+        } else {
+          *reinterpret_cast<float4*>(dst) = float4{src[0], src[1], src[2], src[3]};
+        }
+      }
+    }
+  };
+
+  const bool has_ctrl = MODE != IRBFN_ROLLOUT_SPIRAL;
+  const int ngroups = T / TS;                    // full 4-step groups; the < 4 remaining steps go out as dwords
+  const bool vec = has_ctrl && !last_tile;       // the aligned superset may reach past the buffer end on the last tile
+  if (vec && ngroups > 0) fetch_ctrl(0);
+#pragma unroll 1
+  for (int gI = 0; gI < ngroups; ++gI) {
+    const int t0 = gI * TS;
+    float ua[TS], us[TS];
+    if (has_ctrl) {
+      if (vec) {
+        float keep[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep[i] = mine[i];      // carry lives in [0, 3): untouched by stash_ctrl
+        (void)keep;
+        stash_ctrl();
+        wave_sync();
+        const int sha = (int)((reinterpret_cast<uintptr_t>(urow + t0) >> 2) & 3);
+        const int shs = (int)((reinterpret_cast<uintptr_t>(urow + T + t0) >> 2) & 3);
+#pragma unroll
+        for (int i = 0; i < TS; ++i) { ua[i] = mine[3 + sha + i]; us[i] = mine[3 + 8 + shs + i]; }
+        wave_sync();
+        if (gI + 1 < ngroups) fetch_ctrl(t0 + TS);          // one group ahead
+      } else {
+#pragma unroll
+        for (int i = 0; i < TS; ++i) { ua[i] = urow[t0 + i]; us[i] = urow[T + t0 + i]; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TS; ++i) { ua[i] = 0.0f; us[i] = 0.0f; }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TS; ++tt) {
+      if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[tt], us[tt], a.dp);
+      else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[tt], us[tt], a.dp);
+      else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[tt], us[tt]);
+      else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[tt], us[tt], a.dp);
+      else spiral_step(s, coef, slen, t0 + tt, T);
+#pragma unroll
+      for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
+    }
+    wave_sync();
+    flush(t0, t0 == 0);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                // carry the last C floats to the front of the window
+      const float v = mine[CF + i];
+      if (i < myC) mine[i] = v;
+    }
+    wave_sync();
+  }
+  // tail: T mod 4 steps, then whatever is left in the window as dwords
+  const int done = ngroups * TS;
+  int fill = myC;
+  for (int t = done; t < T; ++t) {
+    const float ca = has_ctrl ? urow[t] : 0.0f, cs = has_ctrl ? urow[T + t] : 0.0f;
+    if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ca, cs, a.dp);
+    else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ca, cs, a.dp);
+    else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ca, cs);
+    else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ca, cs, a.dp);
+    else spiral_step(s, coef, slen, t, T);
+#pragma unroll
+    for (int i = 0; i < S; ++i) mine[fill + i] = s[i];
+    fill += S;
+  }
+  if (lane < nvalid) {
+    const int first_unflushed = done * S - (done > 0 ? myC : 0);
+    const int skip = done > 0 ? 0 : myC;
+    float* dst = gout + (long)lane * T * S + first_unflushed;
+    for (int i = skip; i < fill; ++i) dst[i - skip] = mine[i];
+  }
+}
+
 template <int MODE>
 static int launch_mode(const RollArgs& a, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
@@ -262,7 +428,15 @@ static int launch_mode(const RollArgs& a, hipStream_t s) {
   const long waves = (a.B + kWave - 1) / kWave;
   const long grid = (waves + kRollWaves - 1) / kRollWaves;
   const size_t lds = (size_t)kRollWaves * kWave * 37 * sizeof(float);
-  hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
+  // measured (ST kinematic, T = 50): lean 35.6 vs 39.9 us at B = 32768, 45.7 vs 46.5 at 65536, but 112 vs 70 at
+  // 131072 and 234 vs 208 at 262144 (its per-group control fetch over-fetches 2x; the big batches are bound by
+  // memory transactions, the small ones by one wave's serial latency) -> lean up to 65536 trajectories
+  const char* le = getenv("IRBFN_ROLL_LEAN");
+  const int lean = le ? atoi(le) : (a.B <= 65536 ? 1 : 0);
+  if (lean)
+    hipLaunchKernelGGL(rollout_fwd_lean_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
+  else
+    hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }

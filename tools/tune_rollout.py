@@ -24,7 +24,7 @@ def t_us(fn, reps=30):
 def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     rng = np.random.default_rng(0)
-    Bs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (32768, 131072, 262144, 1048576)
+    Bs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (8192, 32768, 65536, 131072, 262144, 1048576)
     for B in Bs:
         st = rng.normal(size=(B, 7)).astype(np.float32) * np.array([1, 1, .2, 1, .5, .2, .1], np.float32)
         st[:, 3] = rng.uniform(0.5, 7, B)
