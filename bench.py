@@ -271,7 +271,21 @@ def run_extras(net, params, x, configs, torch):
     rbytes = 4 * Bt * (7 + 2 * T + T * 7)
     out["rollout_st_ks_T50"] = {"traj_per_s": Bt / t, "us": t * 1e6, "batch": Bt,
                                 "hbm_GBs": rbytes / t / 1e9, "hbm_frac": rbytes / t / 1e9 / PEAK_HBM_GBS,
-                                "algorithmic_bytes": rbytes}
+                                "algorithmic_bytes": rbytes,
+                                "note": "per-GPU share of cfg-4: 512 waves on 1024 SIMDs -> bound by one wave's serial "
+                                        "latency (50 dependent steps), not by HBM; see the whole-batch entry"}
+    # the whole cfg-4 batch on ONE GPU: the size at which the roll-out is actually HBM-bound
+    Bw = 262144
+    xw = configs.synth_queries(4, B=Bw)
+    stw = configs.initial_state_from_query(xw)
+    uw = np.random.default_rng(6).normal(0, 2.0, size=(Bw, 2 * T)).astype(np.float32)
+    xuw = torch.from_numpy(np.hstack([stw, uw])).cuda()
+    t = _time(lambda: dynamics.integrate_st_ks_mult(xuw, configs.DYN_PARAMS), 20, torch)
+    wbytes = 4 * Bw * (7 + 2 * T + T * 7)
+    out["rollout_st_ks_T50_whole_cfg4_batch"] = {"traj_per_s": Bw / t, "us": t * 1e6, "batch": Bw,
+                                                 "hbm_GBs": wbytes / t / 1e9, "hbm_frac": wbytes / t / 1e9 / PEAK_HBM_GBS,
+                                                 "algorithmic_bytes": wbytes}
+    del xuw
     # fused planning tick, cfg-4 per-GPU share: 4096 centres, O = 100, B = 32768
     card4 = configs.model_card(4)
     net4 = WCRBFNet.from_config(card4)
