@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "rbf_forward.h"
 #include "rbf_vjp_f16.h"
@@ -380,7 +381,9 @@ int launch_vjp_f16(irbfn_net* net, const float* x, const float* gout, int64_t B,
   const int V = net->DC + 1 + net->OP;
   const size_t ring = (size_t)4 * 2 * vjph_block_bytes(net);
   const size_t red = (size_t)4 * V * (16 * CT + 1) * sizeof(float);
-  const size_t lds = ring > red ? ring : red;
+  size_t lds = ring > red ? ring : red;
+  if (const char* e = getenv("IRBFN_VJP_F16_LDSPAD")) lds += (size_t)atol(e);   // diagnosis: lowers the occupancy
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
   switch (net->DC) {
     case 3: return launch_vjph_dc<3>(a, CT, net->bclass, grid, lds, s);
     case 4: return launch_vjph_dc<4>(a, CT, net->bclass, grid, lds, s);
