@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const Roll
         if (first && part == 0 && C > 0) {       // the window starts before the row: only floats [C, 4) exist
           for (int i = C; i < 4; ++i) dst[i] = src[i];
         } else {
+          // (non-temporal stores measured: 294 vs 196 us at B = 262144 -- the 112-byte runs rely on L2 merging)
           *reinterpret_cast<float4*>(dst) = float4{src[0], src[1], src[2], src[3]};
         }
       }
