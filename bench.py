@@ -136,6 +136,12 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    if world > 1:
+        # N > 1: the other ranks are gone after the timed region -- nothing below may issue a collective (the
+        # training-step extra all-reduces its gradients when a process group is up); CPU baseline and extras are
+        # reported at N = 1 only
+        args.no_cpu_baseline = True
+        args.no_extras = True
 
     # ---- roofline of the dominant kernel (the fused forward): algorithmic work / event time
     kern_s = ev_ms / 1e3 / args.steps
