@@ -98,6 +98,36 @@ int irbfn_net_destroy(irbfn_net* net);
 int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* log_sigs_dev,
                          const float* kernel_dev, const float* bias_dev, void* stream);
 
+/* Per-descriptor options: kernel selection and launch geometry.  The defaults are what the library ships
+ * with; everything else exists for A/B measurements and for the reduced-precision report of BASELINE config 5.
+ * Nothing on the launch path reads the process environment.  value 0 of a geometry option = automatic. */
+typedef enum irbfn_option {
+  IRBFN_OPT_FWD_KERNEL = 0,    /* irbfn_fwd_kernel below; default IRBFN_FWD_AUTO */
+  IRBFN_OPT_FWD_SMALL = 1,     /* 1 (default): B <= 64 runs on the latency kernel K1s; 0: never */
+  IRBFN_OPT_FWD_F16_TERMS = 2, /* 3 (default): hi/lo operand pairs, float32-grade result;
+                                  1: plain f16 operands (~1e-4 relative) -- reporting only */
+  IRBFN_OPT_FWD_F16_MINB = 3,  /* smallest batch K1h takes in automatic mode (default 65) */
+  IRBFN_OPT_FWD_Q = 4,         /* K1: queries per lane (1, 2) */
+  IRBFN_OPT_FWD_NW = 5,        /* K1 / K1m: waves per workgroup */
+  IRBFN_OPT_FWD_QJ = 6,        /* K1m: query tiles per wave (1, 2, 4) */
+  IRBFN_OPT_FWD_F16_S = 7,     /* K1h: centre slices per query group */
+  IRBFN_OPT_FWD_F16_QG = 8,    /* K1h: query groups of 32 per workgroup */
+  IRBFN_OPT_VJP_KERNEL = 9,    /* irbfn_vjp_kernel below; default IRBFN_VJP_AUTO */
+  IRBFN_OPT_VJP_F16_CT = 10,   /* K2h: 16-centre tiles per wave (2 default, 4) */
+  IRBFN_OPT_LDS_PAD = 11,      /* diagnosis: extra dynamic LDS bytes per workgroup of K1h / K2h (lowers occupancy) */
+  IRBFN_OPT_COUNT = 12
+} irbfn_option;
+typedef enum irbfn_fwd_kernel {
+  IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; one region + fast basis + O <= 128: K1h; O > 16: K1m; otherwise K1 */
+  IRBFN_FWD_K1 = 1,   /* rbf_fwd_qlane: all-float32 VALU kernel (any net) */
+  IRBFN_FWD_K1M = 2,  /* rbf_fwd_mfma: Phi x W on the f32-input matrix cores */
+  IRBFN_FWD_K1H = 3   /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
+} irbfn_fwd_kernel;
+typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2 } irbfn_vjp_kernel;
+/* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
+int irbfn_net_set_option(irbfn_net* net, int option, int value);
+int irbfn_net_get_option(const irbfn_net* net, int option, int* value_out);
+
 /* Forward: replaces `WCRBFNet.apply(params, x)` (model.py:169-198; called as
  * `state.apply_fn(state.params, x)` in pred_step, src/irbfn_mpc/irbfn_planner.py:29-32).
  * x_dev[B,D] -> out_dev[B,O].  B = 0 is a no-op. */

@@ -18,12 +18,20 @@ BASIS_ENUM = {"gaussian": 0, "gaussian_wide": 1, "gaussian_wider": 2, "inverse_q
 
 ROLLOUT_ST_SELECT, ROLLOUT_ST_KS, ROLLOUT_FULLINT, ROLLOUT_FRENET_LS, ROLLOUT_SPIRAL = 0, 1, 2, 3, 4
 
+# irbfn_option / irbfn_fwd_kernel / irbfn_vjp_kernel (include/irbfn_hip.h)
+OPTIONS = {"fwd_kernel": 0, "fwd_small": 1, "fwd_f16_terms": 2, "fwd_f16_minb": 3, "fwd_q": 4, "fwd_nw": 5, "fwd_qj": 6,
+           "fwd_f16_s": 7, "fwd_f16_qg": 8, "vjp_kernel": 9, "vjp_f16_ct": 10, "lds_pad": 11}
+FWD_AUTO, FWD_K1, FWD_K1M, FWD_K1H = 0, 1, 2, 3
+VJP_AUTO, VJP_K2, VJP_K2H = 0, 1, 2
+
 # every symbol include/irbfn_hip.h declares: (name, restype, argtypes)
 _vp, _fp, _ip, _i, _i64, _f = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "irbfn_net_create": (_i, [C.POINTER(C.c_void_p), _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _ip, _i]),
     "irbfn_net_destroy": (_i, [_vp]),
     "irbfn_net_set_params": (_i, [_vp, _fp, _fp, _fp, _fp, _vp]),
+    "irbfn_net_set_option": (_i, [_vp, _i, _i]),
+    "irbfn_net_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "irbfn_net_forward": (_i, [_vp, _fp, _fp, _i64, _vp]),
     "irbfn_net_gate": (_i, [_vp, _fp, _fp, _i64, _vp]),
     "irbfn_net_vjp_workspace_bytes": (_i64, [_vp, _i64]),

@@ -67,6 +67,8 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   net->DC = DC; net->OP = OP; net->N = R * K;
   net->S = (DC + 1 + OP + 3) & ~3;
   net->nsplit = nsplit; net->max_ranges = max_ranges > 0 ? max_ranges : 1; net->n_ranges = n_ranges;
+  net->opt[IRBFN_OPT_FWD_SMALL] = 1;
+  net->opt[IRBFN_OPT_FWD_F16_TERMS] = 3;
 
   const size_t tab = (size_t)(nsplit > 0 ? nsplit : 1) * net->max_ranges;
   const size_t nr = (size_t)(n_ranges > 0 ? n_ranges : 1) * (nsplit > 0 ? nsplit : 1);
@@ -125,6 +127,32 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
   if (rc == IRBFN_OK && net->f16_img) rc = launch_pack_f16(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
+}
+
+int irbfn_net_set_option(irbfn_net* net, int option, int value) {
+  if (!net || option < 0 || option >= IRBFN_OPT_COUNT || value < 0) return IRBFN_ERR_BAD_ARG;
+  switch (option) {
+    case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1H) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2H) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_SMALL: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 3) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_Q: if (value > 2) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_NW: if (value > 16) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_QJ: if (value != 0 && value != 1 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_F16_S:
+    case IRBFN_OPT_FWD_F16_QG: if (value > 8) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_VJP_F16_CT: if (value != 0 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_LDS_PAD: if (value > 128 * 1024) return IRBFN_ERR_BAD_ARG; break;
+    default: break;
+  }
+  net->opt[option] = value;
+  return IRBFN_OK;
+}
+
+int irbfn_net_get_option(const irbfn_net* net, int option, int* value_out) {
+  if (!net || !value_out || option < 0 || option >= IRBFN_OPT_COUNT) return IRBFN_ERR_BAD_ARG;
+  *value_out = net->opt[option];
+  return IRBFN_OK;
 }
 
 int irbfn_net_forward(irbfn_net* net, const float* x_dev, float* out_dev, int64_t B, void* stream) {

@@ -79,6 +79,7 @@ struct irbfn_net {
   int* gate_ranges;
   int nsplit, max_ranges, n_ranges;
   bool has_params;
+  int opt[IRBFN_OPT_COUNT];     // irbfn_net_set_option
   char last_name[96];
   int last_grid, last_block;
 

@@ -108,12 +108,11 @@ int launch_gate(irbfn_net* net, const float* x, float* gamma, int64_t B, hipStre
 // ------------------------------------------------------------------------------------------------
 // K1 dispatcher: picks queries-per-lane Q and waves-per-workgroup NW, sizes LDS, launches.
 // ------------------------------------------------------------------------------------------------
-#ifndef IRBFN_F16_DEFAULT
-#define IRBFN_F16_DEFAULT 1        // K1h where eligible: cfg-2 131 vs 142 us, cfg-5 7.5 vs 8.9 ms (K1)
-#endif
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
+// Kernel selection and launch geometry are decided here from the descriptor's shape and its options
+// (irbfn_net_set_option, include/irbfn_hip.h); nothing on the launch path reads the environment.
+static int opt_or(const irbfn_net* net, int key, int dflt) {
+  const int v = net->opt[key];
+  return v > 0 ? v : dflt;           // geometry options: 0 = automatic
 }
 
 static int pow2_floor(int v) {
@@ -131,7 +130,7 @@ static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   int Q = 1;
   const bool q2_compiled = (OP == 2 || OP == 5 || OP == 10);
   if (q2_compiled && a.B >= (long)kWave * 32768) Q = 2;
-  Q = env_int("IRBFN_FWD_Q", Q);
+  Q = opt_or(net, IRBFN_OPT_FWD_Q, Q);
   if (Q != 1 && !(Q == 2 && q2_compiled)) Q = 1;
   const int ROWS = kWave * Q;
   const long tiles = (a.B + ROWS - 1) / ROWS;
@@ -142,8 +141,7 @@ static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   nw = pow2_floor(nw);
   while (nw > 1 && net->N / nw < 32) nw /= 2;
   while (nw * kWave > max_threads) nw /= 2;
-  nw = env_int("IRBFN_FWD_NW", nw);
-  if (nw < 1) nw = 1;
+  nw = opt_or(net, IRBFN_OPT_FWD_NW, nw);
   if (nw * kWave > max_threads) nw = max_threads / kWave;
   // --- LDS: max(stage, gate table) aliased with the reduction buffers
   const int OC = OP < 16 ? OP : 16;
@@ -199,17 +197,18 @@ static void fill_args(irbfn_net* net, FwdArgs& a, const float* x, float* out, in
 // Kept as the "reduction expressed as a dense GEMM" variant that BASELINE config 5 asks to report.
 // For WIDE outputs (O > 16: e.g. 50-step control sequences, O = 100) the picture flips: the weight FMAs
 // dominate and the MFMA issues them ~1.8x more densely than SGPR-operand v_fmac (cfg-4 forward 342 ->
-// 301 us), so K1m is the default there.  IRBFN_FWD_MFMA=0/1 forces K1 / K1m.
+// 301 us), so K1m is preferred over K1 there (behind K1h where that is eligible).
+// IRBFN_OPT_FWD_KERNEL = IRBFN_FWD_K1 / IRBFN_FWD_K1M forces K1 / K1m.
 bool prefer_mfma(const irbfn_net* net) {
-  const int e = env_int("IRBFN_FWD_MFMA", -1);
-  if (!net->recm || e == 0) return false;
-  return e == 1 || net->O > 16;
+  const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
+  if (!net->recm || e == IRBFN_FWD_K1) return false;
+  return e == IRBFN_FWD_K1M || net->O > 16;
 }
 
 static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (!prefer_mfma(net)) return IRBFN_ERR_UNSUPPORTED;
   const bool wide = net->O > 16;
-  int QJ = env_int("IRBFN_FWD_QJ", wide ? 2 : 4);
+  int QJ = opt_or(net, IRBFN_OPT_FWD_QJ, wide ? 2 : 4);
   if (QJ != 1 && QJ != 2 && QJ != 4) QJ = wide ? 2 : 4;
   if (wide && QJ == 4) QJ = 2;                   // QJ = 4 is compiled for NT <= 4 only
   const long tiles = (B + 16 * QJ - 1) / (16 * QJ);
@@ -218,8 +217,7 @@ static int try_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t 
   nw = pow2_floor(nw);
   const int chunks = net->Npad / 16;
   while (nw > 1 && chunks / nw < 2) nw /= 2;
-  nw = env_int("IRBFN_FWD_NW", nw);
-  if (nw < 1) nw = 1;
+  nw = opt_or(net, IRBFN_OPT_FWD_NW, nw);
   if (nw > 16) nw = 16;
   return launch_forward_mfma(net, x, out, B, QJ, nw, s);
 }
@@ -269,22 +267,24 @@ int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, flo
   return run_forward(net, a, false, s);
 }
 
-// K1h (Phi x W on the f16 matrix cores at float32 accuracy, rbf_forward_f16.hip): narrow outputs, one region.
-// IRBFN_FWD_F16 = 0 / 1 forces K1 / K1h; IRBFN_FWD_F16_TERMS = 1 selects the reduced-precision single-product
-// variant (reporting only).  Geometry: S centre slices x QG query groups of 32 per 8-wave block, S chosen so
-// that the launch has >= 16384 waves.
+// K1h (Phi x W on the f16 matrix cores at float32 accuracy, rbf_forward_f16.hip): one region, fast basis,
+// O <= 128.  The default where eligible (cfg-2 131 vs 142 us, cfg-5 7.5 vs 8.9 ms against K1);
+// IRBFN_OPT_FWD_KERNEL forces another kernel, IRBFN_OPT_FWD_F16_TERMS = 1 selects the reduced-precision
+// single-product variant (reporting only; never reachable without that explicit option).  Geometry: S centre
+// slices x QG query groups of 32 per 8-wave block, S chosen so that the launch has >= 16384 waves.
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
+  const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
+  if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
   if (!net->f16_img) return IRBFN_ERR_UNSUPPORTED;
-  const int e = env_int("IRBFN_FWD_F16", IRBFN_F16_DEFAULT);
-  if (e == 0 || B < env_int("IRBFN_FWD_F16_MINB", 65)) return IRBFN_ERR_UNSUPPORTED;
+  if (B < opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65)) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   if (net->O > 16) {
     // wide outputs: block-shared W stream; SW = centre slices per block so that the grid covers the 256 CUs
     int SW = 1;
     while (SW < 4 && (groups * SW + 7) / 8 < 256) SW *= 2;
-    SW = env_int("IRBFN_FWD_F16_S", SW);
+    SW = opt_or(net, IRBFN_OPT_FWD_F16_S, SW);
     if (SW != 1 && SW != 2 && SW != 4) SW = 1;
-    const int QGw = env_int("IRBFN_FWD_F16_QG", 8 / SW);
+    const int QGw = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / SW);
     return launch_forward_f16(net, x, out, B, SW, QGw, 3, s);
   }
   long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
@@ -293,23 +293,30 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   if (S < want && S < 8) S *= 2;
   const int nchunks = (net->N + 31) / 32;
   while (S > 1 && nchunks / S < 2) S /= 2;
-  S = env_int("IRBFN_FWD_F16_S", S);
-  if (S < 1 || S > 8 || S > nchunks) S = 1;
-  int QG = env_int("IRBFN_FWD_F16_QG", 8 / S);
-  if (QG < 1 || S * QG > 8) QG = 1;
-  const int terms = env_int("IRBFN_FWD_F16_TERMS", 3);
-  return launch_forward_f16(net, x, out, B, S, QG, terms == 1 ? 1 : 3, s);
+  S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
+  if (S > 8 || S > nchunks) S = 1;
+  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
+  if (S * QG > 8) QG = 1;
+  const int terms = net->opt[IRBFN_OPT_FWD_F16_TERMS] == 1 ? 1 : 3;
+  return launch_forward_f16(net, x, out, B, S, QG, terms, s);
 }
 
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   if (B == 0) return IRBFN_OK;
-  // K1s: small batches (planner ticks) -> centre-lane latency kernel; IRBFN_FWD_SMALL=0 forces K1
-  if (small_eligible(net, B) && env_int("IRBFN_FWD_SMALL", 1) != 0) {
+  // K1s: small batches (planner ticks) -> centre-lane latency kernel (IRBFN_OPT_FWD_SMALL = 0 disables it)
+  const int forced = net->opt[IRBFN_OPT_FWD_KERNEL];
+  if (forced == IRBFN_FWD_AUTO && small_eligible(net, B) && net->opt[IRBFN_OPT_FWD_SMALL] != 0) {
     const int rc = launch_forward_small(net, x, out, B, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   }
-  if (try_forward_f16(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
-  if (try_forward_mfma(net, x, out, B, s) == IRBFN_OK) return IRBFN_OK;
+  // a kernel that is "not eligible" answers IRBFN_ERR_UNSUPPORTED; every other status (a HIP launch failure
+  // of the preferred kernel in particular) is returned, never papered over by the next kernel in line
+  int rc = try_forward_f16(net, x, out, B, s);
+  if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  if (forced == IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
+  rc = try_forward_mfma(net, x, out, B, s);
+  if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  if (forced == IRBFN_FWD_K1M) return IRBFN_ERR_UNSUPPORTED;
   FwdArgs a;
   fill_args(net, a, x, out, B);
   return run_forward(net, a, false, s);

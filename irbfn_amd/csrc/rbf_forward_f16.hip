@@ -7,16 +7,23 @@
 // (no co-execution on gfx950) but does 8192 FMAs, so moving Phi x W to v_mfma_f32_16x16x32_f16 removes
 // those 10 instructions for 3 (the split below) plus ~6 cycles of MFMA per 64 pairs.
 //
-// Accuracy: f16 has 11 significant bits, so both operands are split into an (hi, lo) pair:
-//     phi' = 2^14 * phi           = ph + pl   (ph = phi' with the low 13 mantissa bits cleared: exact in f16;
-//                                              pl = f16_rtz(phi' - ph): 21-22 significant bits in total)
-//     W'   = W / s_o  (|W'| <= 1) = wh + wl   (round-to-nearest f16 pair: 22 bits; s_o = power of two >= max_k |W[k,o]|)
-//     phi' W' ~= ph*wh + pl*wh + ph*wl          (the f16 x f16 products are exact in f32; pl*wl < 2^-22 is dropped)
-// accumulated in f32 by the MFMA.  2^14 keeps phi' out of the f16 subnormals down to phi = 2^-28; it is
-// folded into the argument of the transcendental (free).  Measured on cfg-2 (tools/proto_f16split.hip):
-// max |err| / sum_k |phi_k W_k| = 6e-8 ... 1.7e-7 -- the f32 FMA chain of K1 measures 3e-6.
+// Accuracy: f16 has 11 significant bits, so both operands are split into an (hi, lo) pair, and the lo halves are
+// stored PRE-SCALED by 2^11 and accumulated in their own accumulator, so that they stay in the f16 normal range
+// wherever the hi half does (no dependence on how a weight compares with its column's maximum):
+//     P  = 2^14 * phi            = ph + pl     ph = the top 11 significant bits of P (exact in f16)
+//                                              pls = f16_rtz(2^11 (P - ph))                       |pls| < 2^15
+//     Ws = 2^15 * W / s_o        = wh + wl     wh = f16_rn(Ws)  (s_o = power of two > max_k |W[k,o]|, |Ws| < 2^15)
+//                                              wls = f16_rn(2^11 (Ws - wh))                       |wls| <= 2^14
+//     A1 += ph * wh              A2 += pls * wh + ph * wls              (f16 x f16 products are exact in f32)
+//     sum_k phi_k W_ko = s_o 2^-29 (A1 + 2^-11 A2)        (the pl*wl term, < 2^-22 relative per pair, is dropped)
+// Both halves of a pair are normal f16 numbers down to phi = 2^-28 and |W| = 2^-29 s_o: every product carries
+// ~22 significant bits whatever the dynamic range inside a weight column; below those floors the absolute error
+// of a factor is 2^-49 (phi) / 2^-50 s_o (W).  The first version of this kernel kept pl and wl unscaled in the
+// same accumulator: wl fell into the f16 subnormals for |W| < 2^-3 s_o and the pair lost one bit per factor of two
+// below that (3e-5 relative at 2^-10 s_o) -- tests/test_gpu_f16.py::test_forward_f16_ill_conditioned_columns.
+// 2^14 is folded into the argument of the transcendental (free).
 // TERMS = 1 keeps only ph*wh (plain f16 operands, ~1e-4): the reduced-precision variant BASELINE config 5
-// asks to report; never the default.
+// asks to report; reachable only through irbfn_net_set_option(IRBFN_OPT_FWD_F16_TERMS), never by default.
 //
 // Layout (v_mfma_f32_16x16x32_f16: A[row l&15][k = 8(l>>4)+j], B[k][col l&15], D[row 4(l>>4)+reg][col l&15]):
 // rows = 16 queries, k = 32 centres of a chunk, cols = outputs.  A lane owns query (l & 15) of each of its
@@ -31,6 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "f16_split.h"
 #include "rbf_forward.h"
 
 namespace irbfn {
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256) void f16_colscale_kernel(const float* __restri
     const float mx = red[0];
     if (mx > 0.0f && mx < 3.0e38f) {             // zero column / Inf / NaN: unscaled
       int e;
-      (void)frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)  ->  2^e >= mx
+      (void)frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)  ->  2^e > mx
       s = ldexpf(1.0f, e);
     }
     oscale[o] = s;
@@ -97,24 +105,24 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
   float* rec = reinterpret_cast<float*>(p) + kk * RF;
   const bool real = n < N;
   for (int j = 0; j < RF - 1; ++j) rec[j] = (real && j < D) ? centers[(size_t)n * D + j] : 0.0f;
-  float sc = 0.0f;                                           // padding centre: phi' = 2^14 exactly, W' = 0
+  float sc = 0.0f;                                           // padding centre: P = 2^kPhiExp exactly, W = 0
   if (real) {
     const float s2 = expf(-2.0f * log_sigs[n]);              // 1/sigma^2 (flax_rbf.py:280)
-    if (bclass == BC_GAUSS) sc = -gscale * 1.4426950408889634f * s2;   // phi' = 2^(r2*sc + 14)
-    else if (bclass == BC_IQ) sc = s2 * 6.103515625e-05f;              // phi' = 1 / (2^-14 + 2^-14 d2)
-    else sc = s2 * 3.725290298461914e-09f;                             // phi' = rsqrt(2^-28 + 2^-28 d2)
+    if (bclass == BC_GAUSS) sc = -gscale * 1.4426950408889634f * s2;   // P = 2^(r2*sc + kPhiExp)
+    else if (bclass == BC_IQ) sc = s2 * kPhiInv;                       // P = 1 / (2^-kPhiExp (1 + d2))
+    else sc = s2 * kPhiInv * kPhiInv;                                  // P = rsqrt(2^-2kPhiExp (1 + d2))
   }
   rec[RF - 1] = sc;
   const int g = kk >> 3, j = kk & 7;
   for (int ct = 0; ct < NT; ++ct) {
-    __half* wh = reinterpret_cast<__half*>(p + (size_t)kF16Chunk * RF * 4 + (size_t)ct * 2 * kF16WBytes);
-    __half* wl = wh + kF16WBytes / 2;
+    _Float16* wh = reinterpret_cast<_Float16*>(p + (size_t)kF16Chunk * RF * 4 + (size_t)ct * 2 * kF16WBytes);
+    _Float16* wl = wh + kF16WBytes / 2;
     for (int oo = 0; oo < 16; ++oo) {
       const int o = ct * 16 + oo;
-      float w = 0.0f;
+      float w = 0.0f;                                        // W / s_o, |.| < 1 (exact scaling)
       if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
-      const __half h = __float2half_rn(w);
-      const __half l = __float2half_rn(w - __half2float(h));
+      _Float16 h, l;
+      split_static_f16(w, h, l);
       wh[(g * 16 + oo) * 8 + j] = h;
       wl[(g * 16 + oo) * 8 + j] = l;
     }
@@ -124,13 +132,16 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
 // ---- kernel ----------------------------------------------------------------------------------------------
 template <int BC>
 __device__ __forceinline__ float f16_arg(float r2, float sc) {
-  if constexpr (BC == BC_GAUSS) return __builtin_fmaf(r2, sc, 14.0f);
-  else if constexpr (BC == BC_IQ) return __builtin_fmaf(r2, sc, 6.103515625e-05f);
-  else return __builtin_fmaf(r2, sc, 3.725290298461914e-09f);
+  if constexpr (BC == BC_GAUSS) return __builtin_fmaf(r2, sc, (float)kPhiExp);
+  else if constexpr (BC == BC_IQ) return __builtin_fmaf(r2, sc, kPhiInv);
+  else return __builtin_fmaf(r2, sc, kPhiInv * kPhiInv);
 }
 
+#ifndef IRBFN_K1H_MIN_WAVES
+#define IRBFN_K1H_MIN_WAVES 2      // waves per SIMD the register allocation must allow (512 threads = 2 per block)
+#endif
 template <int DC, int BC, int TERMS>
-__global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
+__global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(const F16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RF = f16_rf(DC);
   constexpr int RECB = kF16Chunk * RF * 4;                   // record bytes per chunk
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
       if (v * 64 + lane < NV) reinterpret_cast<u4_t*>(dst)[v * 64 + lane] = pre[v];
   };
 
-  f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A1: ph * wh
+  f4_t acl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A2: pls * wh + ph * wls  (2^11 x the lo terms)
   h8_t ah[2], al[2], bh, bl;                                 // operands of the PREVIOUS step (deferred MFMAs)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ah[0][j] = 0; ah[1][j] = 0; al[0][j] = 0; al[1][j] = 0; bh[j] = 0; bl[j] = 0; }
@@ -212,33 +224,23 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
         }
         t16[t * 8 + j] = f16_arg<BC>(r2, r[RF - 1]);
       }
-      // one deferred MFMA per centre: (tile, term) = (j & 1, j >> 1); terms: ph*wh, pl*wh, ph*wl
+      // one deferred MFMA per centre: (tile, term) = (j & 1, j >> 1); terms: ph*wh -> A1; pls*wh, ph*wls -> A2
       const int t = j & 1, m = j >> 1;
       if (m < TERMS) {
         const h8_t av = (m == 1) ? al[t] : ah[t];
         const h8_t bv = (m == 2) ? bl : bh;
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+        if (m == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+        else acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acl[t], 0, 0, 0);
       }
     }
-    trans_block<BC, 16>(t16);                                // phi' = 2^14 * phi for the step's 16 pairs
+    trans_block<BC, 16>(t16);                                // P = 2^kPhiExp * phi for the step's 16 pairs
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      u4_t wh, wl;                                           // 4 packed f16 pairs each = one MFMA A operand
+      unsigned wh[4], wl[4];                                 // 4 packed f16 pairs each = one MFMA A operand
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float p0 = t16[t * 8 + 2 * jj], p1 = t16[t * 8 + 2 * jj + 1];
-        if constexpr (TERMS >= 2) {
-          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
-          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
-          wh[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-          wl[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
-        } else {
-          wh[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-          wl[jj] = 0u;
-        }
-      }
-      ah[t] = __builtin_bit_cast(h8_t, wh);
-      al[t] = __builtin_bit_cast(h8_t, wl);
+      for (int jj = 0; jj < 4; ++jj) split_pair_f16<TERMS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+      ah[t] = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
+      al[t] = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
     }
     bh = nbh; bl = nbl;
     if (has_next) store_rec(nxt, pre);
@@ -248,8 +250,11 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t], 0, 0, 0);
-    if constexpr (TERMS >= 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t], 0, 0, 0);
-    if constexpr (TERMS >= 3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t], 0, 0, 0);
+    if constexpr (TERMS >= 2) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t], 0, 0, 0);
+    if constexpr (TERMS >= 3) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acl[t], 0, 0, 0);
+    if constexpr (TERMS >= 2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], kLoScale, acc[t][r]);   // A1 + 2^-11 A2
   }
 
   // ---- smooth region gate of the single region (model.py:42-95), one value per query
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma(const F16Args a) {
   if (slice == 0 && g == 0) { gl[qg * 32 + n] = gam[0]; gl[qg * 32 + 16 + n] = gam[1]; }
   __syncthreads();
   if (slice == 0 && n < a.O) {
-    const float sc = a.oscale[n] * 6.103515625e-05f;         // s_o * 2^-14
+    const float sc = a.oscale[n] * (1.0f / (16384.0f * kWScale));                // s_o * 2^-29
     const float bi = a.bias[n];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -345,11 +350,11 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
     for (int v = 0; v < MAXP; ++v)
       if (v * team + st < NV) reinterpret_cast<u4_t*>(dst)[v * team + st] = pre[v];
   };
-  f4_t acc[2][NT];
+  f4_t acc[2][NT], acl[2][NT];                               // A1, A2 (header)
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[t][ct] = f4_t{0, 0, 0, 0};
+    for (int ct = 0; ct < NT; ++ct) { acc[t][ct] = f4_t{0, 0, 0, 0}; acl[t][ct] = f4_t{0, 0, 0, 0}; }
   if (c0 < c1) { fetch(c0); stash(stream); }
   __syncthreads();
   for (int i = 0; i < nsteps; ++i) {
@@ -383,17 +388,13 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
       trans_block<BC, 16>(t16);
       h8_t ah[2], al[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        unsigned wh[4], wl[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float p0 = t16[t * 8 + 2 * jj], p1 = t16[t * 8 + 2 * jj + 1];
-          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
-          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
-          const h2_t hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
-          const h2_t ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
-          ah[t][2 * jj] = (_Float16)hh[0]; ah[t][2 * jj + 1] = (_Float16)hh[1];
-          al[t][2 * jj] = (_Float16)ll[0]; al[t][2 * jj + 1] = (_Float16)ll[1];
-        }
+        for (int jj = 0; jj < 4; ++jj) split_pair_f16<3>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+        ah[t] = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
+        al[t] = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
+      }
       // W operands of tile ct + 1 are read while the 6 MFMAs of tile ct run (the LDS latency is otherwise
       // exposed 7 times per step: hipcc issues each read right in front of its first use)
       h8_t bh = *reinterpret_cast<const h8_t*>(cur + RECB + lane * 16);
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][ct], 0, 0, 0);
-          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][ct], 0, 0, 0);
-          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][ct], 0, 0, 0);
+          acl[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t][ct], 0, 0, 0);
+          acl[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acl[t][ct], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         bh = nbh; bl = nbl;
@@ -444,11 +445,12 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((slice * QG + qg) * 2 + t) * 4 + r) * 64 + lane] = acc[t][ct][r];
+      for (int r = 0; r < 4; ++r)
+        red[(((slice * QG + qg) * 2 + t) * 4 + r) * 64 + lane] = __builtin_fmaf(acl[t][ct][r], kLoScale, acc[t][ct][r]);
     __syncthreads();
     const int o = ct * 16 + n;
     if (slice == 0 && o < a.O) {
-      const float sc = a.oscale[o] * 6.103515625e-05f;
+      const float sc = a.oscale[o] * (1.0f / (16384.0f * kWScale));
       const float bi = a.bias[o];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -592,7 +594,7 @@ int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, in
   const size_t ring = (size_t)waves * 2 * kF16Chunk * f16_rf(net->DC) * 4;
   const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
   size_t lds = ring > red ? ring : red;
-  if (const char* e = getenv("IRBFN_FWD_F16_LDSPAD")) lds += (size_t)atol(e);   // diagnosis: lowers the occupancy
+  lds += (size_t)net->opt[IRBFN_OPT_LDS_PAD];               // diagnosis only: lowers the occupancy
   if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   const int grid = (int)((groups + QG - 1) / QG);

@@ -18,9 +18,6 @@
 #include "rbf_forward.h"
 #include "rbf_vjp_f16.h"
 
-#ifndef IRBFN_VJP_F16_DEFAULT
-#define IRBFN_VJP_F16_DEFAULT 1     // K2h where eligible (cfg-3: 336 vs 394 us)
-#endif
 
 namespace irbfn {
 
@@ -286,11 +283,6 @@ struct VjpPlan {
   int CT;
 };
 
-static int vjp_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   VjpPlan p;
   p.groups = (net->N + kWave - 1) / kWave;
@@ -316,9 +308,10 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   p.off_bias = off;  off += al((size_t)p.bias_blocks * net->O * sizeof(float));
   p.QS = (net->DC + 1 + net->OP + 3) & ~3;
   p.off_qrec = off;  off += al((size_t)B * p.QS * sizeof(float));
-  // K2h: packed 32-query blocks + (absmax, scales); IRBFN_VJP_F16 = 0 / 1 forces K2 / K2h
-  p.use_h = vjph_eligible(net) && B >= 2048 && vjp_env_int("IRBFN_VJP_F16", IRBFN_VJP_F16_DEFAULT) != 0;
-  p.CT = vjp_env_int("IRBFN_VJP_F16_CT", 2) == 4 ? 4 : 2;
+  // K2h: packed 32-query blocks + (absmax, scales); IRBFN_OPT_VJP_KERNEL = IRBFN_VJP_K2 / IRBFN_VJP_K2H forces one
+  const int vk = net->opt[IRBFN_OPT_VJP_KERNEL];
+  p.use_h = vjph_eligible(net) && vk != IRBFN_VJP_K2 && B >= 2048;
+  p.CT = net->opt[IRBFN_OPT_VJP_F16_CT] == 4 ? 4 : 2;
   p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * vjph_block_bytes(net) : 0);
   p.off_misc = off;  off += al((size_t)(p.bias_blocks + 8) * sizeof(float));
   if (p.use_h) {

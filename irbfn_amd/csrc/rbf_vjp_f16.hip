@@ -1,5 +1,6 @@
 // K2h: parameter VJP of the single-region RBF net with its two GEMM-shaped pieces on the f16 matrix cores at
-// float32 accuracy (same hi/lo operand split as the forward kernel K1h, rbf_forward_f16.hip):
+// float32 accuracy (hi/lo operand pairs with the lo halves pre-scaled by 2^11 and accumulated separately,
+// f16_split.h -- no loss for cotangent rows far below the batch maximum or weights far below their column's):
 //     hbar[q,k] = sum_o g[q,o] W[k,o]        (v_mfma_f32_16x16x16_f16: rows = queries, cols = centres, k = outputs)
 //     dW[k,o]   = sum_q gamma_q phi[q,k] g[q,o]   (v_mfma_f32_16x16x16_f16: rows = outputs, cols = centres, k = queries)
 // and everything else (distances, basis, d centers, d log_sigs; SURVEY App. A.2, jax.value_and_grad at
@@ -18,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "f16_split.h"
 #include "rbf_forward.h"
 #include "rbf_vjp_f16.h"
 
@@ -28,6 +30,7 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef __fp16 h2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 // ---- pre-pass ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pow2_ceil_scale(float mx) {
@@ -88,9 +91,10 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
       const int o = 4 * g + j;
       float v = 0.0f;
       if (q < B && o < O) v = gout[q * O + o] * (oscale[o] / sh);
-      const _Float16 h = (_Float16)v;
+      _Float16 h, l;
+      split_static_f16(v, h, l);
       hi[j] = h;
-      lo[j] = (_Float16)(v - (float)h);
+      lo[j] = l;
     }
     gA[(s * 2 + 0) * 64 + lane] = hi;
     gA[(s * 2 + 1) * 64 + lane] = lo;
@@ -106,9 +110,10 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
       const long q = q0 + 16 * s + 4 * g + j;
       float v = 0.0f;
       if (q < B && n < O) v = gout[q * O + n] / sg;
-      const _Float16 h = (_Float16)v;
+      _Float16 h, l;
+      split_static_f16(v, h, l);
       hi[j] = h;
-      lo[j] = (_Float16)(v - (float)h);
+      lo[j] = l;
     }
     gT[(s * 2 + 0) * 64 + lane] = hi;
     gT[(s * 2 + 1) * 64 + lane] = lo;
@@ -142,7 +147,8 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
   const int cb = blockIdx.x * 16 * CT;
   const float sg = a.scales[0], sh = a.scales[1];
   // s_h times the constant of dphi/dd2 (gaussian family: -a; inverse quadratic: -1; inverse multiquadric: -1/2)
-  const float shk = sh * (BC == BC_GAUSS ? -a.gscale : (BC == BC_IQ ? -1.0f : -0.5f));
+  // (and 2^-30: both operands of the hbar product carry 2^15)
+  const float shk = sh * (1.0f / (kWScale * kWScale)) * (BC == BC_GAUSS ? -a.gscale : (BC == BC_IQ ? -1.0f : -0.5f));
 
   float c[CT][DC], sc[CT], s2m2[CT];
   h4v wth[CT], wtl[CT];
@@ -159,17 +165,19 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
     for (int j = 0; j < 4; ++j) {
       const int o = 4 * g + j;
       const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] : 0.0f;
-      const _Float16 h = (_Float16)w;
+      _Float16 h, l;
+      split_static_f16(w, h, l);
       wth[ct][j] = h;
-      wtl[ct][j] = (_Float16)(w - (float)h);
+      wtl[ct][j] = l;
     }
   }
   float gc[CT][DC], gls[CT];
-  f4v dW[CT];
+  f4v dW[CT], dWl[CT];                                       // A1, A2 of the dW product (f16_split.h)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     gls[ct] = 0.0f;
     dW[ct] = f4v{0, 0, 0, 0};
+    dWl[ct] = f4v{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < DC; ++j) gc[ct][j] = 0.0f;
   }
@@ -213,12 +221,15 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
       f4v hb[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
+        f4v hl = f4v{0, 0, 0, 0};
         hb[ct] = f4v{0, 0, 0, 0};
         hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wth[ct], hb[ct], 0, 0, 0);
-        hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gal, wth[ct], hb[ct], 0, 0, 0);
-        hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wtl[ct], hb[ct], 0, 0, 0);
+        hl = __builtin_amdgcn_mfma_f32_16x16x16f16(gal, wth[ct], hl, 0, 0, 0);
+        hl = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wtl[ct], hl, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[ct][r] = __builtin_fmaf(hl[r], kLoScale, hb[ct][r]);
       }
-      float hq[CT][4];                                        // 2^14 gamma phi of this lane's 4 queries of the half
+      float hq[CT][4];                                        // 2^kPhiExp gamma phi of this lane's 4 queries of the half
 #pragma unroll
       for (int r0 = 0; r0 < 4; r0 += RQ) {
         float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], gm16[RQ], kq[RQ];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
             const f4v rr = *reinterpret_cast<const f4v*>(xr + 4 * v);
             xv[4 * v] = rr.x; xv[4 * v + 1] = rr.y; xv[4 * v + 2] = rr.z; xv[4 * v + 3] = rr.w;
           }
-          gm16[u] = xv[RFQ - 1] * 16384.0f;
+          gm16[u] = xv[RFQ - 1] * kPhiScale;
           kq[u] = xv[RFQ - 1] * shk;                          // gamma * s_h * (basis constant of dphi/dd2)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
@@ -269,20 +280,14 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
       const h4v gtl = *reinterpret_cast<const h4v*>(cur + QXB + 2048 + ((s * 2 + 1) * 64 + lane) * 8);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        h4v bh, bl;
+        unsigned bh2[2], bl2[2];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const float p0 = hq[ct][2 * jj], p1 = hq[ct][2 * jj + 1];
-          const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
-          const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
-          const h2v hh = __builtin_amdgcn_cvt_pkrtz(h0, h1);
-          const h2v ll = __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1);
-          bh[2 * jj] = (_Float16)hh[0]; bh[2 * jj + 1] = (_Float16)hh[1];
-          bl[2 * jj] = (_Float16)ll[0]; bl[2 * jj + 1] = (_Float16)ll[1];
-        }
+        for (int jj = 0; jj < 2; ++jj) split_pair_f16<3>(hq[ct][2 * jj], hq[ct][2 * jj + 1], bh2[jj], bl2[jj]);
+        const h4v bh = __builtin_bit_cast(h4v, u2v{bh2[0], bh2[1]});
+        const h4v bl = __builtin_bit_cast(h4v, u2v{bl2[0], bl2[1]});
         dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bh, dW[ct], 0, 0, 0);
-        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gtl, bh, dW[ct], 0, 0, 0);
-        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bl, dW[ct], 0, 0, 0);
+        dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gtl, bh, dWl[ct], 0, 0, 0);
+        dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bl, dWl[ct], 0, 0, 0);
       }
     }
     if (has_next) stash(nxt);
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
   const int V = DC + 1 + a.OP;
   constexpr int COLS = 16 * CT;
   float* red = reinterpret_cast<float*>(lds);                 // [4][V][COLS + 1]
-  const float wscale = sg * 6.103515625e-05f;                 // s_g * 2^-14
+  const float wscale = sg * (1.0f / (16384.0f * kWScale));    // s_g * 2^-14 (phi) * 2^-15 (cotangent)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int col = ct * 16 + n;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = 4 * g + r;
-      if (o < a.OP) red[(wave * V + DC + 1 + o) * (COLS + 1) + col] = dW[ct][r] * wscale;
+      if (o < a.OP) red[(wave * V + DC + 1 + o) * (COLS + 1) + col] = __builtin_fmaf(dWl[ct][r], kLoScale, dW[ct][r]) * wscale;
     }
   }
   __syncthreads();
@@ -382,7 +387,7 @@ int launch_vjp_f16(irbfn_net* net, const float* x, const float* gout, int64_t B,
   const size_t ring = (size_t)4 * 2 * vjph_block_bytes(net);
   const size_t red = (size_t)4 * V * (16 * CT + 1) * sizeof(float);
   size_t lds = ring > red ? ring : red;
-  if (const char* e = getenv("IRBFN_VJP_F16_LDSPAD")) lds += (size_t)atol(e);   // diagnosis: lowers the occupancy
+  lds += (size_t)net->opt[IRBFN_OPT_LDS_PAD];               // diagnosis only: lowers the occupancy
   if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
   switch (net->DC) {
     case 3: return launch_vjph_dc<3>(a, CT, net->bclass, grid, lds, s);

@@ -153,6 +153,17 @@ class WCRBFNet:
             self._handles[dev] = h
         return h
 
+    def set_options(self, **opts) -> "WCRBFNet":
+        """Per-descriptor kernel selection / launch geometry (``irbfn_net_set_option``; names = keys of
+        ``_lib.OPTIONS``, e.g. ``fwd_kernel=_lib.FWD_K1``).  For A/B measurements and the reduced-precision
+        report of BASELINE config 5; the defaults are the product path."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        h = self._handle(torch)
+        for k, v in opts.items():
+            _lib.check(lib.irbfn_net_set_option(h, _lib.OPTIONS[k], int(v)), f"irbfn_net_set_option({k}={v})")
+        return self
+
     def __del__(self):
         try:
             lib = _lib.load()

@@ -82,8 +82,8 @@ def test_forward_trained_checkpoints(gpu, run):
 
 
 @pytest.mark.parametrize("run", CKPT_RUNS)
-def test_small_batch_kernel_and_tiled_kernel_agree(gpu, run, monkeypatch):
-    """B <= 64 dispatches to the centre-lane latency kernel (K1s); IRBFN_FWD_SMALL=0 forces the tiled
+def test_small_batch_kernel_and_tiled_kernel_agree(gpu, run):
+    """B <= 64 dispatches to the centre-lane latency kernel (K1s); the option fwd_kernel = K1 forces the tiled
     query-lane kernel (K1, incl. its gated R > 1 path).  Both must meet the oracle and each other."""
     cfg, params, x, out64, h64, _ = load_ckpt_fixture(run)
     net = WCRBFNet.from_config(cfg)
@@ -92,7 +92,7 @@ def test_small_batch_kernel_and_tiled_kernel_agree(gpu, run, monkeypatch):
     assert "clane" in net.last_launch()["kernel"]
     one = net.apply(params, x32[:1])                          # the planner's B = 1 call
     np.testing.assert_array_equal(one, net.apply(params, x32[:1]))   # fixed-order reduction: deterministic
-    monkeypatch.setenv("IRBFN_FWD_SMALL", "0")
+    net.set_options(fwd_kernel=_lib.FWD_K1)
     b = net.apply(params, x32)
     assert "qlane" in net.last_launch()["kernel"]
     scale = np.abs(h64) @ np.abs(np.asarray(params["params"]["linear"]["kernel"], np.float64))
