@@ -36,7 +36,8 @@ UNITS = [
     ("rbf_forward_small.hip", "rbf_fwd_small.o", []),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
-    ("rollout.hip", "rollout.o", []),
+    # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace
+    ("rollout.hip", "rollout.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
     ("rollout_vjp.hip", "rollout_vjp.o", []),
     ("train_step.hip", "train_step.o", []),
     ("mlp_head.hip", "mlp_head.o", []),

@@ -9,22 +9,16 @@
 // into the range of its hi half, it is a NORMAL f16 number wherever the hi half is one: every factor keeps ~22
 // significant bits over the whole f16 exponent range -- 2^-14 <= |2^E v| < 2^16 -- i.e. for the scales used here
 // (E chosen so that max |2^E v| is in [2^14, 2^15)) down to 2^-29 of the largest magnitude the scale was taken
-// from; below that the absolute error of a factor is <= 2^-36 of that magnitude.  The first round kept the
+// from; below that the hi half itself is an f16 subnormal and the absolute error of a factor is <= 2^-39 of that
+// magnitude (for the basis value: float32-grade terms for phi >= 2^-28, absolute error <= 2^-38 per unit weight
+// below -- measured: tools/probe_single_term.py, profiles/r02_f16_pair_precision.txt).  The first round kept the
 // residual unscaled in the same accumulator: it fell into the f16 subnormals as soon as |v| < 2^-3 of the
 // maximum and the pair lost a bit per factor of two below that (3e-5 relative at 2^-10).
 #pragma once
 
-#ifndef IRBFN_F16_SPLIT
-#define IRBFN_F16_SPLIT 1                        // 1: mask / subtract / scale; 3: v_fma_mix form (split_pair_f16)
-#endif
-
 namespace irbfn {
 
-#if IRBFN_F16_SPLIT == 3
-constexpr int kPhiExp = 25;                      // the basis value arrives as 2^25 phi, its hi half is 2^-11 of it
-#else
 constexpr int kPhiExp = 14;                      // the basis value arrives as P = 2^14 phi (<= 2^14)
-#endif
 constexpr float kPhiScale = (float)(1 << kPhiExp);
 constexpr float kPhiInv = 1.0f / kPhiScale;
 constexpr int kWExp = 15;                        // static factors (weights, cotangents): 2^15 v / s, |.| < 2^15
@@ -33,29 +27,23 @@ constexpr float kLoScale = 1.0f / 2048.0f;       // A1 + kLoScale * A2
 constexpr float kLoGain = 2048.0f;
 
 // Two basis values p0, p1 (scaled by 2^kPhiExp, non-negative) -> packed f16 pairs: hi = 2^14 phi to 11 bits,
-// lo = 2^11 x (2^14 phi - hi).  TERMS == 1: plain f16 operands (reduced precision, reporting only).
-template <int TERMS>
+// lo = 2^11 x (2^14 phi - hi) (LOS) or the unscaled residual (!LOS: one v_mul per value cheaper; the pair then
+// keeps ~22 bits only for phi >= 2^-17 and carries an absolute error <= 2^-38 below -- the lo product goes into
+// A1).  TERMS == 1: plain f16 operands (reduced precision, reporting only).
+template <int TERMS, bool LOS = true>
 __device__ __forceinline__ void split_pair_f16(float p0, float p1, unsigned& hi, unsigned& lo) {
-  if constexpr (TERMS >= 2) {
-#if IRBFN_F16_SPLIT == 3
-    // hi = f16_rn(2^-11 p) and r = p - 2^11 hi (exact) through the mixed-precision FMAs: 5 instructions per pair
-    const float c1 = 4.8828125e-04f, c2 = -2048.0f;
-    unsigned hh = 0;
-    float r0, r1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hh) : "v"(p0), "v"(c1));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hh) : "v"(p1), "v"(c1));
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh), "v"(c2), "v"(p0));
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh), "v"(c2), "v"(p1));
-    hi = hh;
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-#else
+  if constexpr (TERMS >= 2 && !LOS) {
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
+    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
+  } else if constexpr (TERMS >= 2) {
     const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p0) & 0xFFFFE000u);
     const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p1) & 0xFFFFE000u);
     hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((p0 - h0) * kLoGain, (p1 - h1) * kLoGain));
-#endif
   } else {
-    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0 * (kPhiInv * 16384.0f), p1 * (kPhiInv * 16384.0f)));
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
     lo = 0u;
   }
 }

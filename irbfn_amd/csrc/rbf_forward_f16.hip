@@ -47,6 +47,8 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;   // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int kF16Chunk = 32;                    // centres per chunk = MFMA K
 constexpr int kF16WBytes = 4 * 16 * 8 * 2;       // one W part of a chunk: [g][n][8] halfs = 1 KiB
@@ -137,6 +139,9 @@ __device__ __forceinline__ float f16_arg(float r2, float sc) {
   else return __builtin_fmaf(r2, sc, kPhiInv * kPhiInv);
 }
 
+#ifndef IRBFN_K1H_PHI_LOS
+#define IRBFN_K1H_PHI_LOS 1        // 1: residual of the basis value pre-scaled by 2^11 (A2); 0: unscaled (A1)
+#endif
 #ifndef IRBFN_K1H_MIN_WAVES
 #define IRBFN_K1H_MIN_WAVES 2      // waves per SIMD the register allocation must allow (512 threads = 2 per block)
 #endif
@@ -166,22 +171,23 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int i = 0; i < DC; ++i) asm volatile("" : "+v"(xq[t][i]));   // loads complete before the loop
-  unsigned char* mylds = lds + wave * (2 * RECB);
+  // Wave-private double-buffered ring of chunk images [records | W hi | W lo], filled by LDS-DMA
+  // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging VGPRs, no ds_write pass) one step ahead.
+  constexpr int WB = (TERMS >= 3 ? 2 : 1) * kF16WBytes;      // W bytes staged per chunk
+  constexpr int BUFB = RECB + 2 * kF16WBytes;
+  unsigned char* mylds = lds + wave * (2 * BUFB);
   const int c0 = (int)((long)a.nchunks * slice / S), c1 = (int)((long)a.nchunks * (slice + 1) / S);
-  auto wave_sync = [&]() {                                   // wave-private ring: in-order LDS queue suffices
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  auto fetch_rec = [&](const unsigned char* gp, u4_t (&pre)[(NV + 63) / 64]) {
+  auto stage = [&](int c, unsigned char* dst) {              // chunk c -> dst (asynchronous; retired by vmcnt)
+    const unsigned char* gp = a.img + (size_t)c * CB + lane * 16;
 #pragma unroll
     for (int v = 0; v < (NV + 63) / 64; ++v)
-      if (v * 64 + lane < NV) pre[v] = reinterpret_cast<const u4_t*>(gp)[v * 64 + lane];
-  };
-  auto store_rec = [&](unsigned char* dst, const u4_t (&pre)[(NV + 63) / 64]) {
+      if (v * 64 + lane < NV)
+        __builtin_amdgcn_global_load_lds((gptr_t)(gp + v * 1024),
+                                         (lptr_t)(dst + v * 1024), 16, 0, 0);
 #pragma unroll
-    for (int v = 0; v < (NV + 63) / 64; ++v)
-      if (v * 64 + lane < NV) reinterpret_cast<u4_t*>(dst)[v * 64 + lane] = pre[v];
+    for (int v = 0; v < WB / 1024; ++v)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gp + RECB + v * 1024),
+                                       (lptr_t)(dst + RECB + v * 1024), 16, 0, 0);
   };
 
   f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A1: ph * wh
@@ -189,21 +195,14 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
   h8_t ah[2], al[2], bh, bl;                                 // operands of the PREVIOUS step (deferred MFMAs)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ah[0][j] = 0; ah[1][j] = 0; al[0][j] = 0; al[1][j] = 0; bh[j] = 0; bl[j] = 0; }
-  u4_t pre[(NV + 63) / 64];
-  if (c0 < c1) {
-    fetch_rec(a.img + (size_t)c0 * CB, pre);
-    store_rec(mylds, pre);
-  }
-  wave_sync();
+  if (c0 < c1) stage(c0, mylds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int c = c0; c < c1; ++c) {
-    const unsigned char* cur = mylds + ((c - c0) & 1) * RECB;
-    unsigned char* nxt = mylds + ((c - c0 + 1) & 1) * RECB;
-    const unsigned char* gp = a.img + (size_t)c * CB;
-    const bool has_next = c + 1 < c1;
-    if (has_next) fetch_rec(gp + CB, pre);
-    const h8_t nbh = *reinterpret_cast<const h8_t*>(gp + RECB + lane * 16);
-    h8_t nbl = nbh;
-    if constexpr (TERMS >= 3) nbl = *reinterpret_cast<const h8_t*>(gp + RECB + kF16WBytes + lane * 16);
+    const unsigned char* cur = mylds + ((c - c0) & 1) * BUFB;
+    unsigned char* nxt = mylds + ((c - c0 + 1) & 1) * BUFB;
+    // every LDS read of the previous step (records and W of `nxt`) has returned before the DMA overwrites it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c + 1 < c1) stage(c + 1, nxt);
     float t16[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
       if (m < TERMS) {
         const h8_t av = (m == 1) ? al[t] : ah[t];
         const h8_t bv = (m == 2) ? bl : bh;
-        if (m == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+        if (m == 0 || (m == 1 && !IRBFN_K1H_PHI_LOS)) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
         else acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acl[t], 0, 0, 0);
       }
     }
@@ -238,19 +237,21 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
     for (int t = 0; t < 2; ++t) {
       unsigned wh[4], wl[4];                                 // 4 packed f16 pairs each = one MFMA A operand
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) split_pair_f16<TERMS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+      for (int jj = 0; jj < 4; ++jj)
+        split_pair_f16<TERMS, IRBFN_K1H_PHI_LOS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
       ah[t] = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
       al[t] = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
     }
-    bh = nbh; bl = nbl;
-    if (has_next) store_rec(nxt, pre);
-    wave_sync();
+    bh = *reinterpret_cast<const h8_t*>(cur + RECB + lane * 16);              // this chunk's W operands (B layout)
+    if constexpr (TERMS >= 3) bl = *reinterpret_cast<const h8_t*>(cur + RECB + kF16WBytes + lane * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // chunk c + 1 has landed in `nxt`
   }
   // drain the deferred MFMAs of the last step
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t], 0, 0, 0);
-    if constexpr (TERMS >= 2) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t], 0, 0, 0);
+    if constexpr (TERMS >= 2 && IRBFN_K1H_PHI_LOS) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t], 0, 0, 0);
+    if constexpr (TERMS >= 2 && !IRBFN_K1H_PHI_LOS) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t], 0, 0, 0);
     if constexpr (TERMS >= 3) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acl[t], 0, 0, 0);
     if constexpr (TERMS >= 2)
 #pragma unroll
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
       for (int t = 0; t < 2; ++t) {
         unsigned wh[4], wl[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) split_pair_f16<3>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+        for (int jj = 0; jj < 4; ++jj)
+          split_pair_f16<3, IRBFN_K1H_PHI_LOS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
         ah[t] = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
         al[t] = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
       }
@@ -410,7 +412,8 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16mfma_wide(const F16Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][ct], 0, 0, 0);
-          acl[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t][ct], 0, 0, 0);
+          if constexpr (IRBFN_K1H_PHI_LOS) acl[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t][ct], 0, 0, 0);
+          else acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][ct], 0, 0, 0);
           acl[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acl[t][ct], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -591,7 +594,7 @@ int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, in
   a.x = x; a.img = net->f16_img; a.oscale = net->f16_oscale; a.bias = net->bias; a.out = out; a.gate = net->gate();
   a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.nchunks = nchunks; a.S = S; a.QG = QG;
   const int waves = S * QG;
-  const size_t ring = (size_t)waves * 2 * kF16Chunk * f16_rf(net->DC) * 4;
+  const size_t ring = (size_t)waves * 2 * (kF16Chunk * f16_rf(net->DC) * 4 + 2 * kF16WBytes);
   const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
   size_t lds = ring > red ? ring : red;
   lds += (size_t)net->opt[IRBFN_OPT_LDS_PAD];               // diagnosis only: lowers the occupancy

@@ -54,7 +54,8 @@ struct RollArgs {
   float* __restrict__ states;      // [B][T][S]
   long B;
   int T, L;
-  int dbg;                         // diagnosis only (IRBFN_ROLL_DBG): 1 = skip stores, 2 = skip control loads
+  int wlds;                        // floats of LDS per wave (regs kernel)
+  int dma_ok;                      // input buffers 16-byte aligned: whole-tile LDS-DMA prologue allowed
   DynParams dp;
 };
 
@@ -63,202 +64,205 @@ struct RollArgs {
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kRollWaves = 4;      // waves per workgroup (independent; wave-private LDS)
-constexpr int kRollTS = 4;         // steps staged per flush = controls fetched per 16-byte load
+constexpr int kRollTS = 4;         // lean kernel: steps staged per flush = controls fetched per 16-byte load
+constexpr int kRollRPP = 16;       // regs kernel: rows per LDS-DMA input pass
+#ifndef IRBFN_ROLL_GROUP
+#define IRBFN_ROLL_GROUP 12
+#endif
+constexpr int kRollGroup = IRBFN_ROLL_GROUP;   // regs kernel: steps per unrolled group (multiple of the flush chunk)
+constexpr int roll_pitch(int S, int TS) { return (TS * S + 3) | 1; }   // floats per row window, odd
+typedef const __attribute__((address_space(1))) void* gptr_t;          // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-// What makes this kernel fast (each item measured, profiles/r01_rollout_*, tools/ubench_mem.hip):
-//  * occupancy: one step is a long DEPENDENT chain, so a SIMD needs several resident waves; LDS is
-//    one 64 x 37-float tile per wave (9.5 KB), shared by the input and the output staging;
-//  * straight-line sin/cos/tan (rollout_step.h) instead of ocml's branchy range reduction;
-//  * only ALIGNED 16-byte HBM accesses.  Rows are merely dword aligned and gfx950 splits unaligned
-//    16-byte accesses (112-byte row runs: 2.2 TB/s unaligned float4 vs 4.2 TB/s aligned float2).
-//    - stores: sliding window.  Row r's buffer starts C_r floats before the chunk so that it begins
-//      on a 16-byte boundary of HBM; TS*S = 0 (mod 4), hence every flush emits exactly TS*S/4
-//      aligned float4 per row and carries the same C_r trailing floats into the next chunk; only
-//      the first C_r-complement and the last < 4 floats of a row are written as dwords.
-//    - loads: per 8-step chunk the aligned float4 superset of a[t0..t0+8) (<= 3 pieces per row) is
-//      fetched cooperatively, 21 rows per instruction, all loads of a stream issued back to back.
-//  * measured and rejected: a whole-128-byte-line flush (64-float ring per row, 20 KB LDS per wave):
-//    187-195 us vs 205 us at B = 262144 but 49-54 us vs 40 us at B = 32768 -- the store phase costs
-//    ~100 us whatever the pattern (a 367 MB fill alone takes 64 us), so the simpler window stays.
-template <int MODE>
-__global__ __launch_bounds__(64 * kRollWaves) void rollout_fwd_kernel(const RollArgs a) {
+// K3 `rollout_fwd_regs_kernel<MODE, TCH, TS>`: the roll-out for horizons T <= TCH (BASELINE config 4: T = 50).
+// HBM-bound by its bytes (1828 B per trajectory at T = 50 against ~8 kFLOP); what it takes to get there:
+//  * every input row is touched ONCE.  A wave's 64 rows are one contiguous block of HBM (64 L floats); it is copied
+//    in RPP-row passes by LDS-DMA (global_load_lds_dwordx4: whole aligned kilobytes, no staging VGPRs) and each
+//    lane then pulls its own row into REGISTERS: the 2T controls of a trajectory live in VGPRs for the whole
+//    roll-out (the register file is the one on-chip store large enough: 428 B per trajectory in flight; LDS is
+//    not).  Round 1 fetched per-row control chunks twice per stream: FETCH_SIZE 2.6x the algorithmic bytes.
+//  * the step loop is unrolled in groups (static register indices, rotated between groups), everything that
+//    depends on T is wave-uniform;
+//  * states leave through a wave-private LDS tile of TS steps x 64 rows as ALIGNED 16-byte stores: row r's window
+//    starts C_r floats before its chunk so that it begins on a 16-byte boundary of HBM; the C_r = (C_r + TS*S) mod 4
+//    trailing floats are carried to the next window, only the first 4 - C_r and the last < 4 floats of a row go
+//    out as dwords.  The pieces of a flush are dealt to the lanes densely (piece = j*64 + lane): no idle lanes;
+//  * nothing in the loop waits for memory: the stores are fire-and-forget (no load is outstanding after the
+//    prologue, so no s_waitcnt vmcnt is ever needed), LDS hazards are the wave's own in-order queue.
+// Bit-identical to the other roll-out kernels: the step functions are shared (rollout_step.h, no contraction).
+#ifndef IRBFN_ROLL_MINW
+#define IRBFN_ROLL_MINW 3          // waves per SIMD the long-horizon instance is allocated for (100 control VGPRs)
+#endif
+template <int MODE, int TCH, int TS>
+__global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) void rollout_fwd_regs_kernel(const RollArgs a) {
   extern __shared__ float lds[];
   constexpr int S = ModeTraits<MODE>::S;
   constexpr int S0 = ModeTraits<MODE>::S0;
-  constexpr int TS = kRollTS;
   constexpr int CF = TS * S;                     // floats per full output chunk per row
-  constexpr int NP = CF / 4;                     // aligned float4 pieces per row per flush
-  constexpr int TCH = 32;                        // steps per control chunk
-  constexpr int PITCH = 37;                      // >= max(CF + 3, 4*PPR), odd -> conflict-free row access
-  static_assert(CF % 4 == 0 && CF + 3 <= PITCH && NP <= 8, "sliding-window flush needs TS*S = 0 (mod 4)");
+  constexpr int NP = CF / 4;                     // whole 16-byte pieces per row window and flush ((C + CF) >> 2, C < 4)
+  constexpr int PITCH = roll_pitch(S, TS);       // odd: conflict-free per-lane row access
+  constexpr int RPP = kRollRPP;                  // rows per input pass
+  constexpr bool HAS_U = MODE != IRBFN_ROLLOUT_SPIRAL;
+  static_assert(CF % 4 == 0, "sliding-window flush: TS*S = 0 (mod 4) keeps the carry constant");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long b0 = ((long)blockIdx.x * kRollWaves + wave) * kWave;
   if (b0 >= a.B) return;                         // whole wave out of range (no block-level barriers used)
   const long left = a.B - b0;
   const int nvalid = left < kWave ? (int)left : kWave;
-  const bool last_tile = left <= kWave;          // reads near the end of the input buffer stay scalar
   const int T = a.T;
-  const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
-  const float* row = a.x0 + bb * a.L0;           // initial state (or spiral parameters)
-  const float* urow = a.u + bb * a.LU;           // this lane's controls
-  float* tile = lds + wave * (kWave * PITCH);
+  float* tile = lds + (size_t)wave * a.wlds;
   float* mine = tile + lane * PITCH;
-  auto wave_sync = [&]() {                       // wave-private LDS: in-order queue, no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  auto lds_drain = [&]() {                       // wave-private LDS: the wave's own reads / writes have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  float* gout = a.states + b0 * (long)T * S;     // tile base in HBM; row stride T*S
-  // leading floats of a row's window that belong to the previous 16-byte block: C = (addr / 4) mod 4
-  auto carry_of = [&](int r) { return (int)((reinterpret_cast<uintptr_t>(gout + (long)r * T * S) >> 2) & 3); };
-  const int myC = carry_of(lane < nvalid ? lane : 0);
 
+  // ---- prologue: this lane's row -> registers -------------------------------------------------------------
   float s[S];
+  float ua[TCH], us[TCH];
+#pragma unroll
+  for (int t = 0; t < TCH; ++t) { ua[t] = 0.0f; us[t] = 0.0f; }
+  float q0[S0];                                  // raw leading floats of the row (state / spiral parameters)
+  const bool dma = nvalid == kWave && a.dma_ok;  // tail tile / unaligned buffers: per-lane loads
+  if (dma) {
+    const bool split = a.x0 != a.u - S0 || a.L0 != a.LU;     // state rows and control rows in separate buffers
+#pragma unroll 1
+    for (int p = 0; p < kWave / RPP; ++p) {
+      // pass p: rows [p*RPP, (p+1)*RPP) of the tile, contiguous in HBM, as whole 16-byte pieces
+      const long r0 = b0 + (long)p * RPP;
+      int nf0, nf1 = 0;                          // floats of region 0 (rows incl. state) and region 1 (split: controls)
+      const float* src0 = a.x0 + r0 * a.L0;
+      const float* src1 = nullptr;
+      if (split) { nf0 = RPP * (int)a.L0; nf1 = RPP * (int)a.LU; src1 = a.u + r0 * a.LU; }
+      else nf0 = RPP * (int)a.L0;
+      for (int v = lane * 4; v < nf0; v += 256)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src0 + v), (lptr_t)(tile + (v - lane * 4)), 16, 0, 0);
+      for (int v = lane * 4; v < nf1; v += 256)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src1 + v), (lptr_t)(tile + nf0 + (v - lane * 4)), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if ((lane / RPP) == p) {
+        const float* rr = tile + (lane % RPP) * (int)a.L0;
+#pragma unroll
+        for (int i = 0; i < S0; ++i) q0[i] = rr[i];
+        if constexpr (HAS_U) {
+          const float* ur = split ? tile + nf0 + (lane % RPP) * (int)a.LU : rr + S0;
+#pragma unroll
+          for (int t = 0; t < TCH; ++t) {        // u = [a_0.., sv_0..] (dynamics.py:98); slots t >= T are never used
+            ua[t] = ur[t];                       // (an LDS read past the wave's tile returns junk or 0, never faults)
+            us[t] = ur[T + t];
+          }
+        }
+      }
+      lds_drain();
+    }
+  } else {
+    const long bb = b0 + (lane < nvalid ? lane : nvalid - 1);
+    const float* row = a.x0 + bb * a.L0;
+    const float* urow = a.u + bb * a.LU;
+#pragma unroll
+    for (int i = 0; i < S0; ++i) q0[i] = row[i];
+    if constexpr (HAS_U) {
+#pragma unroll
+      for (int t = 0; t < TCH; ++t)
+        if (t < T) { ua[t] = urow[t]; us[t] = urow[T + t]; }
+    }
+  }
   [[maybe_unused]] float coef[4];
   [[maybe_unused]] float slen = 0.0f;
   if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
     s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
-    s[3] = clipf(row[0], 0.0f, 7.0f);            // train_nmpc.py:319
+    s[3] = clipf(q0[0], 0.0f, 7.0f);             // train_nmpc.py:319
   } else if constexpr (MODE == IRBFN_ROLLOUT_SPIRAL) {
-    float q[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) q[i] = row[i];
-    spiral_coefs(q, coef);
-    slen = q[4];
+    spiral_coefs(q0, coef);
+    slen = q0[4];
     s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[3] = coef[0]; s[4] = 0.0f; s[5] = 0.0f;   // planner_utils.py:67-70
   } else {
 #pragma unroll
-    for (int i = 0; i < S; ++i) s[i] = row[i];
+    for (int i = 0; i < S; ++i) s[i] = q0[i];
   }
 
-  // cooperative aligned fetch of one control stream chunk: floats [g0, g0 + n) of every row, g0 = r*L + off
-  auto fetch_stream = [&](int off, int n, float (&dst)[TCH]) {
-    if (last_tile || (a.dbg & 2)) {              // scalar path (tail tile / diagnosis)
+  // ---- steps + sliding-window flush ------------------------------------------------------------------------
+  float* gout = a.states + b0 * (long)T * S;     // tile base in HBM; row stride T*S
+  const long rs = (long)T * S;
+  const int gC = (int)((reinterpret_cast<uintptr_t>(gout) >> 2) & 3);
+  auto carry_of = [&](int r) { return (gC + (int)((r * rs) & 3)) & 3; };   // floats of row r's window before its start
+  const int myC = carry_of(lane);
+  // pieces [0, npc_r) of every row window -> aligned float4 in HBM; nfl = floats the chunk added to each window
+  auto flush = [&](int t0, int nfl) {
 #pragma unroll
-      for (int i = 0; i < TCH; ++i) dst[i] = (a.dbg & 2) ? 0.25f : (i < n ? urow[off + i] : 0.0f);
-      return;
-    }
-    const float* tin = a.u + b0 * a.LU;
-    constexpr int PPR = (TCH + 3 + 3) / 4, RPI = kWave / PPR, NI = (kWave + RPI - 1) / RPI;   // pieces/row, rows/instr
-    const int rsub = lane / PPR, part = lane - rsub * PPR;
-    float4 v[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {               // all loads first: one wait for the whole stream chunk
-      int r = j * RPI + rsub;
-      r = (r < nvalid && rsub < RPI) ? r : 0;
-      const float* g0 = tin + (long)r * a.LU + off;
-      // aligned-down pointer by ARITHMETIC on g0 (an integer round trip loses the address space: hipcc then emits
-      // flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) after every single load, which also drains the pending stores)
-      const float* al = g0 - (int)((reinterpret_cast<uintptr_t>(g0) >> 2) & 3);
-      v[j] = *reinterpret_cast<const float4*>(al + 4 * part);
-    }
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int r = j * RPI + rsub;
-      if (r < nvalid && rsub < RPI) {
-        float* t = tile + r * PITCH + 4 * part;
-        t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
-      }
-    }
-    wave_sync();
-    const int sh = (int)((reinterpret_cast<uintptr_t>(urow + off) >> 2) & 3);  // my row's offset inside piece 0
-#pragma unroll
-    for (int i = 0; i < TCH; ++i) dst[i] = i < n ? mine[sh + i] : 0.0f;
-    wave_sync();
-  };
-
-  // cooperative flush of the row windows: pieces [4p, 4p+4) of each row's buffer -> aligned float4 in HBM
-  auto flush = [&](int t0, bool first) {
-    const int rsub = lane >> 3, part = lane & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                // 8 x (4 LDS reads + 1 aligned 16-byte store)
-      const int r = j * 8 + rsub;
-      if (r < nvalid && part < NP) {
+    for (int j = 0; j < NP; ++j) {
+      const int idx = j * kWave + lane;
+      const int r = idx / NP, part = idx - r * NP;
+      if (r < nvalid) {
         const int C = carry_of(r);
-        const float* src = tile + r * PITCH + 4 * part;
-        float* dst = gout + (long)r * T * S + (long)t0 * S - C + 4 * part;     // 16-byte aligned
-        if (a.dbg & 1) continue;
-        if (first && part == 0 && C > 0) {       // the window starts before the row: only floats [C, 4) exist
-          for (int i = C; i < 4; ++i) dst[i] = src[i];
-        } else {
-          // (non-temporal stores measured: 294 vs 196 us at B = 262144 -- the 112-byte runs rely on L2 merging)
-          *reinterpret_cast<float4*>(dst) = float4{src[0], src[1], src[2], src[3]};
+        const int npc = (C + nfl) >> 2;          // whole pieces available in this row's window
+        if (part < npc) {
+          const float* src = tile + r * PITCH + 4 * part;
+          float* dst = gout + r * rs + (long)t0 * S - C + 4 * part;     // 16-byte aligned
+          const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+          if (t0 == 0 && part == 0 && C > 0) {   // the window starts before the row: only floats [C, 4) exist
+            if (C <= 1) dst[1] = v1;
+            if (C <= 2) dst[2] = v2;
+            dst[3] = v3;
+          } else {
+            *reinterpret_cast<float4*>(dst) = float4{v0, v1, v2, v3};
+          }
         }
       }
     }
   };
-
-  int fill = myC;                                // floats in my window (the first C are carry / padding)
+  int rem = myC;                                 // floats left in my window after the last flush
+  // The step loop is ROLLED over groups of G steps (a straight-line 50-step body is ~70 KB of code: measured
+  // instruction-fetch bound, 68 us per wave); inside a group the controls sit at static register indices, between
+  // groups the control registers rotate down by G (2 (TCH - G) v_mov per group, ~5 % of a group's instructions).
+  constexpr int G = TCH < kRollGroup ? ((TCH + TS - 1) / TS) * TS : kRollGroup;
+  static_assert(G % TS == 0, "group = whole flush chunks");
+  const int ngroups = (T + G - 1) / G;
 #pragma unroll 1
-  for (int tc = 0; tc < T; tc += TCH) {
-    float ua[TCH], us[TCH];
-    if constexpr (MODE != IRBFN_ROLLOUT_SPIRAL) {
-      const int n = (T - tc) < TCH ? (T - tc) : TCH;
-      // the carry lives in the tile: park it in registers while the tile stages the controls
-      float keep[3];
+  for (int gI = 0; gI < ngroups; ++gI) {
+    const int tg = gI * G;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) keep[i] = mine[i];
-      wave_sync();
-      fetch_stream(tc, n, ua);                   // u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98)
-      fetch_stream(T + tc, n, us);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) mine[i] = keep[i];
-    }
-#pragma unroll
-    for (int ts = 0; ts < TCH; ts += TS) {
-      const int t0 = tc + ts;
-      if (t0 + TS <= T) {                        // full chunk
+    for (int t0 = 0; t0 < G; t0 += TS) {
+      if (tg + t0 < T) {                         // wave-uniform
+        const int n = (T - tg - t0) < TS ? (T - tg - t0) : TS;
 #pragma unroll
         for (int tt = 0; tt < TS; ++tt) {
-          if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[ts + tt], us[ts + tt], a.dp);
-          else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[ts + tt], us[ts + tt], a.dp);
-          else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[ts + tt], us[ts + tt]);
-          else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[ts + tt], us[ts + tt], a.dp);
-          else spiral_step(s, coef, slen, t0 + tt, T);
-#pragma unroll
-          for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
-        }
-        wave_sync();
-        flush(t0, t0 == 0);
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {            // carry the last C floats to the front of the window
-          const float v = mine[CF + i];
-          if (i < myC) mine[i] = v;
-        }
-        fill = myC;
-      } else if (t0 < T) {                       // partial last chunk: dword stores
-        const int tn = T - t0;
-#pragma unroll
-        for (int tt = 0; tt < TS - 1; ++tt) {      // static register indices (no scratch)
-          if (tt < tn) {
-            if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[ts + tt], us[ts + tt], a.dp);
-            else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[ts + tt], us[ts + tt], a.dp);
-            else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[ts + tt], us[ts + tt]);
-            else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[ts + tt], us[ts + tt], a.dp);
-            else spiral_step(s, coef, slen, t0 + tt, T);
+          if (t0 + tt < TCH && tt < n) {
+            if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua[t0 + tt], us[t0 + tt], a.dp);
+            else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[t0 + tt], us[t0 + tt], a.dp);
+            else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[t0 + tt], us[t0 + tt]);
+            else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[t0 + tt], us[t0 + tt], a.dp);
+            else spiral_step(s, coef, slen, tg + t0 + tt, T);
 #pragma unroll
             for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
           }
         }
-        fill = myC + tn * S;
+        lds_drain();
+        flush(tg + t0, n * S);
+        // carry the floats behind the last whole piece to the front of the window (full chunk: again myC of them)
+        const int tot = myC + n * S;
+        rem = tot & 3;
+        float c0 = mine[(tot & ~3) + 0], c1 = mine[(tot & ~3) + 1], c2 = mine[(tot & ~3) + 2];
+        lds_drain();
+        mine[0] = c0; mine[1] = c1; mine[2] = c2;
       }
     }
+    if constexpr (HAS_U && TCH > G) {
+#pragma unroll
+      for (int i = 0; i + G < TCH; ++i) { ua[i] = ua[i + G]; us[i] = us[i + G]; }
+    }
   }
-  // epilogue: whatever is left in my window (carry, or carry + partial chunk) goes out as dwords
-  if (lane < nvalid && !(a.dbg & 1)) {
-    const int done = (T / TS) * TS;              // steps covered by full chunks
-    const int first_unflushed = done * S - (done > 0 ? myC : 0);
-    const int skip = done > 0 ? 0 : myC;         // no full chunk was flushed: window still has its padding
-    float* dst = gout + (long)lane * T * S + first_unflushed;
-    for (int i = skip; i < fill; ++i) dst[i - skip] = mine[i];
+  // epilogue: the < 4 floats left in my window go out as dwords
+  if (lane < nvalid) {
+    float* dst = gout + lane * rs + rs - rem;
+    for (int i = 0; i < rem; ++i) dst[i] = mine[i];
   }
 }
 
-// K3b: the same roll-out with a ROLLED step loop.  The 32-step unroll of rollout_fwd_kernel keeps 64 control
-// values in VGPRs (239 VGPRs -> 2 waves per SIMD), which leaves the LDS-read -> store latency of every flush
-// exposed.  Here a group of 4 steps is the unit: the group's controls (2 streams x 4 values per row) are staged
+// K3b: the roll-out with a ROLLED step loop, for horizons beyond the unroll depth of rollout_fwd_regs_kernel.
+// A group of 4 steps is the unit: the group's controls (2 streams x 4 values per row) are staged
 // through the SAME tile that stages the group's output states (aligned 16-byte pieces fetched one group ahead
 // into 4 VGPRs per lane), so a wave needs ~90 VGPRs and one 9.5 KB tile: 4 waves per SIMD.
 template <int MODE>
@@ -422,22 +426,43 @@ __global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(co
   }
 }
 
+#ifndef IRBFN_ROLL_TS
+#define IRBFN_ROLL_TS 4            // steps per flush of the regs kernel (TS * S = 0 mod 4)
+#endif
+constexpr int kRollTchLong = 50, kRollTchShort = 8;    // compiled unroll depths: T <= 8 (the reference's 5), T <= 50
+
 template <int MODE>
-static int launch_mode(const RollArgs& a, hipStream_t s) {
+static int launch_mode(const RollArgs& a0, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
-  (void)S;
+  constexpr int TS = (MODE == IRBFN_ROLLOUT_SPIRAL && (IRBFN_ROLL_TS & 1)) ? IRBFN_ROLL_TS + 1 : IRBFN_ROLL_TS;
+  RollArgs a = a0;
   const long waves = (a.B + kWave - 1) / kWave;
   const long grid = (waves + kRollWaves - 1) / kRollWaves;
+  if (a.T <= kRollTchLong) {
+    // K3: controls in registers, whole-tile LDS-DMA input, fire-and-forget aligned stores
+    const bool has_u = MODE != IRBFN_ROLLOUT_SPIRAL;
+    const bool split = has_u && (a.x0 != a.u - ModeTraits<MODE>::S0 || a.L0 != a.LU);
+    long in_floats = (long)kRollRPP * (a.L0 + (split ? a.LU : 0));
+    long w = (long)kWave * roll_pitch(S, TS);
+    if (in_floats > w) w = in_floats;
+    a.wlds = (int)((w + 3) & ~3L);
+    a.dma_ok = ((reinterpret_cast<uintptr_t>(a.x0) | reinterpret_cast<uintptr_t>(a.u)) & 15) == 0 ||
+               (!split && (reinterpret_cast<uintptr_t>(a.x0) & 15) == 0);
+    const size_t lds = (size_t)kRollWaves * a.wlds * sizeof(float);
+    if (lds <= 64 * 1024) {
+      if (a.T <= kRollTchShort)
+        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchShort, TS>), dim3((unsigned)grid), dim3(kWave * kRollWaves),
+                           lds, s, a);
+      else
+        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchLong, TS>), dim3((unsigned)grid), dim3(kWave * kRollWaves),
+                           lds, s, a);
+      IRBFN_HIP_CHECK(hipGetLastError());
+      return IRBFN_OK;
+    }
+  }
+  // longer horizons: rolled 4-step groups, controls staged through LDS group by group
   const size_t lds = (size_t)kRollWaves * kWave * 37 * sizeof(float);
-  // measured (ST kinematic, T = 50): lean 35.6 vs 39.9 us at B = 32768, 45.7 vs 46.5 at 65536, but 112 vs 70 at
-  // 131072 and 234 vs 208 at 262144 (its per-group control fetch over-fetches 2x; the big batches are bound by
-  // memory transactions, the small ones by one wave's serial latency) -> lean up to 65536 trajectories
-  const char* le = getenv("IRBFN_ROLL_LEAN");
-  const int lean = le ? atoi(le) : (a.B <= 65536 ? 1 : 0);
-  if (lean)
-    hipLaunchKernelGGL(rollout_fwd_lean_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
-  else
-    hipLaunchKernelGGL(rollout_fwd_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
+  hipLaunchKernelGGL(rollout_fwd_lean_kernel<MODE>, dim3((unsigned)grid), dim3(kWave * kRollWaves), lds, s, a);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -478,7 +503,8 @@ int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, floa
   a.states = states;
   a.B = (long)B;
   a.T = T;
-  a.dbg = getenv("IRBFN_ROLL_DBG") ? atoi(getenv("IRBFN_ROLL_DBG")) : 0;
+  a.wlds = 0;
+  a.dma_ok = 0;
   a.dp = dp;
   return dispatch_mode(mode, a, s);
 }
@@ -498,7 +524,8 @@ int launch_rollout_forward_split(int mode, const float* state0, const float* con
   a.states = states;
   a.B = (long)B;
   a.T = T;
-  a.dbg = 0;
+  a.wlds = 0;
+  a.dma_ok = 0;
   a.dp = dp;
   return dispatch_mode(mode, a, s);
 }

@@ -4,23 +4,22 @@
 
 #include "common.h"
 
+#ifndef IRBFN_ROLL_IEEE_DIV
+#define IRBFN_ROLL_IEEE_DIV 0      // 1: IEEE division sequences everywhere (A/B; KAT-1 is met to 1e-6 either way)
+#endif
+
 namespace irbfn {
 
-// Straight-line sin/cos for the roll-outs.  ocml's sinf/cosf/tanf cost ~430 VALU instructions per
-// step with divergent range-reduction branches; one step is a serial dependent chain, so the stand-
-// alone roll-out was latency bound at 14-24 % of HBM.  Here: Cody-Waite reduction by pi/2 with three
-// FMA steps (exact to |x| < 8192, beyond that the ocml path), cephes minimax polynomials on
-// [-pi/4, pi/4] (<= 1 ulp each), quadrant select.  Total error <= 2 ulp; one reduction serves sin and cos.
-__device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
-  if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) {   // huge, inf or nan: accurate slow path
-    sn = sinf(x);
-    cs = cosf(x);
-    return;
-  }
-  const float kf = rintf(x * 0.636619772367581343f);  // x * 2/pi
-  float r = __builtin_fmaf(-kf, 1.57079625129699707031e+00f, x);
-  r = __builtin_fmaf(-kf, 7.54978941586159635335e-08f, r);
-  r = __builtin_fmaf(-kf, 5.39030285815811905290e-15f, r);
+// Straight-line sin/cos for the roll-outs.  ocml's sinf/cosf/tanf cost ~430 VALU instructions per step with
+// divergent range-reduction branches, and their inlined bodies (one copy per call site) made the unrolled step
+// loops instruction-fetch bound.  Here: Cody-Waite reduction by pi/2 with three FMA steps, cephes minimax
+// polynomials on [-pi/4, pi/4] (<= 1 ulp each), quadrant select; total error <= 2 ulp, one reduction serves sin
+// and cos.  The FMAs keep the float32 reduction accurate while k = rint(x 2/pi) is off by at most one, i.e. for
+// |x| < 2^22 (every partial remainder is O(1) and rounded once).  Beyond that (rare, divergent, a dozen f64
+// instructions -- no call: a call makes hipcc drain vmcnt, i.e. wait for every outstanding store, in each step)
+// the reduction runs in float64, exact for |x| < 2^52; inf / nan give nan.  Float32 angles >= 2^52 have a spacing
+// >= 2^29 rad: the remainder is clamped and the result is SOME value in [-1, 1] (documented divergence).
+__device__ __forceinline__ void sincos_poly(float r, int k, float& sn, float& cs) {
   const float r2 = r * r;
   float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
   sp = __builtin_fmaf(sp, r2, -1.6666654611e-1f);
@@ -28,22 +27,69 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
   float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
   cp = __builtin_fmaf(cp, r2, 4.166664568298827e-2f);
   cp = __builtin_fmaf(cp * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
-  const int k = (int)kf;
   const float a = (k & 1) ? cp : sp;                  // sin: sp, cp, -sp, -cp
   const float b = (k & 1) ? sp : cp;                  // cos: cp, -sp, -cp, sp
   sn = (k & 2) ? -a : a;
   cs = ((k + 1) & 2) ? -b : b;
 }
 
+// |x| known to be < 2^22 (e.g. a clipped steering angle); nan in -> nan out
+__device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
+  const float kf = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  float r = __builtin_fmaf(-kf, 1.57079625129699707031e+00f, x);
+  r = __builtin_fmaf(-kf, 7.54978941586159635335e-08f, r);
+  r = __builtin_fmaf(-kf, 5.39030285815811905290e-15f, r);
+  sincos_poly(r, (int)kf, sn, cs);
+}
+
+__device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
+  const float kf = rintf(x * 0.636619772367581343f);
+  float r = __builtin_fmaf(-kf, 1.57079625129699707031e+00f, x);
+  r = __builtin_fmaf(-kf, 7.54978941586159635335e-08f, r);
+  r = __builtin_fmaf(-kf, 5.39030285815811905290e-15f, r);
+  int k = (int)kf;
+  if (__builtin_expect(!(fabsf(x) < 4194304.0f), 0)) {
+    const double xd = (double)x;
+    const double kd = __builtin_rint(xd * 0.63661977236758134308);
+    double rd = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+    rd = __builtin_fma(-kd, 6.12323399573676603587e-17, rd);
+    rd = rd < -0.7853981633974483 ? -0.7853981633974483 : (rd > 0.7853981633974483 ? 0.7853981633974483 : rd);   // nan stays
+    r = (float)rd;
+    k = (int)(kd - 4.0 * __builtin_floor(kd * 0.25));
+  }
+  sincos_poly(r, k, sn, cs);
+}
+
+// a / b by reciprocal + one correction step (<= 1 ulp; 4 instructions instead of the ~10 of the IEEE sequence).
+// Only where b is never 0 / inf / subnormal: cos of a float (never exactly 0), the wheelbase.
+__device__ __forceinline__ float fdiv_fast(float a, float b) {
+#if IRBFN_ROLL_IEEE_DIV
+  return a / b;
+#else
+  const float rc = __builtin_amdgcn_rcpf(b);
+  const float q = a * rc;
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), rc, q);
+#endif
+}
+
 __device__ __forceinline__ float tan_fast(float x) {
   float sn, cs;
   sincos_fast(x, sn, cs);
-  return sn / cs;
+  return fdiv_fast(sn, cs);
+}
+// tan of an angle clipped to [-bound, bound]; `small` = bound < 2^22 (wave-uniform)
+__device__ __forceinline__ float tan_clipped(float x, bool small) {
+  float sn, cs;
+  if (small) sincos_small(x, sn, cs);
+  else sincos_fast(x, sn, cs);
+  return fdiv_fast(sn, cs);
 }
 
 __device__ __forceinline__ float clipf(float v, float lo, float hi) {
-  // jnp.clip = min(max(v, lo), hi); NaN propagates (fmaxf alone would swallow it)
-  return v != v ? v : fminf(fmaxf(v, lo), hi);
+  // jnp.clip = min(max(v, lo), hi), nan propagates.  v_med3_f32 (nan in -> min3) + one select: 3 instructions
+  // (fminf(fmaxf()) canonicalises every operand: 7)
+  const float m = __builtin_amdgcn_fmed3f(v, lo, hi);
+  return v != v ? v : m;
 }
 
 // Single-track model, src/irbfn_mpc/dynamics.py:9-91.  SELECT=true: x + select(V>3, f, f_ks)*dt (:90);
@@ -80,7 +126,7 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
     sincos_fast(PSI, sn, cs);
     f0 = V * cs;
     f1 = V * sn;
-    f4 = (V / (lr + lf)) * tan_fast(DELTA);
+    f4 = fdiv_fast(V, lr + lf) * tan_clipped(DELTA, s_max < 4194304.0f);
     f5 = 0.0f;
     f6 = 0.0f;
   }
@@ -103,7 +149,7 @@ __device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv) {
   s[1] = s[1] + s[3] * sn * DT;                          // :361
   s[2] = clipf(s[2] + dv * DT, -SMAX, SMAX);             // :362-363
   s[3] = clipf(s[3] + a * DT, VMIN, VMAX);               // :364-365
-  s[4] = s[4] + (s[3] / WB) * tan_fast(s[2]) * DT;       // :366
+  s[4] = s[4] + fdiv_fast(s[3], WB) * tan_clipped(s[2], true) * DT;       // :366
 }
 
 // Frenet model, low-speed RHS only, src/irbfn_mpc/dynamics.py:190-281 (:267-280).
@@ -118,7 +164,7 @@ __device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_
   sincos_fast(epsi, se, ce);
   const float d0 = (vx * ce) / (1.0f - ey * cur);        // :268
   const float d1 = vx * se;                              // :269
-  const float d6 = (vx * tan_fast(delta)) / (LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
+  const float d6 = fdiv_fast(vx * tan_clipped(delta, s_max < 4194304.0f), LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
   s[0] = s[0] + d0 * dt;
   s[1] = s[1] + d1 * dt;
   s[2] = s[2] + dv * dt;

@@ -348,3 +348,26 @@ def test_vjp_f16_ill_conditioned_cotangents(gpu, case):
     ra, rb = np.abs(ga - gr) / rowmax, np.abs(gb - gr) / rowmax
     print(f"{case} centers: K2h max {ra.max():.2e}  K2 {rb.max():.2e}")
     assert ra.max() <= max(1e-5, 3.0 * rb.max()), (case, ra.max(), rb.max())
+
+
+def test_forward_f16_far_queries_error_floor(gpu):
+    """Queries far from every centre (all basis values tiny): the documented floor of the f16 pairs
+    (f16_split.h) -- float32-grade terms down to phi = 2^-28, absolute error <= 2^-38 per unit weight below."""
+    K, O, B = 512, 10, 1024
+    rng, cfg, centers, log_sigs = _cond_net(K, O, "gaussian", seed=3)
+    centers[:] = rng.uniform(0, 1, size=centers.shape)
+    log_sigs[:] = 0.0
+    W = (np.abs(rng.normal(size=(K, O))) + 0.05).astype(np.float32)
+    params = {"params": {"rbf_list": {"centers": centers, "log_sigs": log_sigs},
+                         "linear": {"kernel": W, "bias": np.zeros(O, np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    p64 = orc.cast_params(params, np.float64)
+    for shift, rel_tol in ((0.0, 2e-6), (2.0, 2e-6), (3.0, 3e-6), (4.0, None), (5.0, None)):
+        x = rng.uniform(0, 1, size=(B, 7)).astype(np.float32)
+        x[:, 0] += shift
+        got, _ = _run(net, params, x)
+        ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+        err = np.abs(got - ref)
+        if rel_tol is not None:
+            assert (err / ref).max() <= rel_tol, (shift, (err / ref).max())
+        assert (err <= 3e-6 * ref + 2.0 ** -38 * W.sum(axis=0)[None, :]).all(), shift

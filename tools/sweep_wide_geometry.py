@@ -6,7 +6,7 @@ card = configs.model_card(4); net = WCRBFNet.from_config(card); net.bind(distrib
 for B in (32768,):
     x = torch.from_numpy(configs.synth_queries(4, B=B)).cuda()
     for S, QG in ((2,4),(2,2),(1,4),(1,2),(4,2),(1,8)):
-        os.environ["IRBFN_FWD_F16_S"]=str(S); os.environ["IRBFN_FWD_F16_QG"]=str(QG)
+        net.set_options(fwd_f16_s=S, fwd_f16_qg=QG)
         net(x); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
