@@ -62,15 +62,19 @@ struct RollArgs {
 // 16-byte vector with 4-byte alignment: the input rows are only dword aligned (L is odd), gfx950
 // handles the unaligned global_load_dwordx4
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+#ifndef IRBFN_ROLL_NT
+#define IRBFN_ROLL_NT 1            // whole-line stores non-temporal: 107 vs 149 us at B = 262144 (they need no merging in L2 / the
+                                   // memory-side cache, and the write-back of a 367 MB stream through it is what limited the rate)
+#endif
 
 constexpr int kRollWaves = 4;      // waves per workgroup (independent; wave-private LDS)
 constexpr int kRollTS = 4;         // lean kernel: steps staged per flush = controls fetched per 16-byte load
 constexpr int kRollRPP = 16;       // regs kernel: rows per LDS-DMA input pass
-#ifndef IRBFN_ROLL_GROUP
-#define IRBFN_ROLL_GROUP 12
-#endif
-constexpr int kRollGroup = IRBFN_ROLL_GROUP;   // regs kernel: steps per unrolled group (multiple of the flush chunk)
-constexpr int roll_pitch(int S, int TS) { return (TS * S + 3) | 1; }   // floats per row window, odd
+constexpr int kRegsWaves = 2;      // regs kernel: waves per workgroup (17 KB of LDS each)
+
+constexpr int roll_pitch(int S, int TS) { return (31 + TS * S) | 1; }   // floats per row window (leftover < 32 + one chunk), odd
+constexpr int roll_ts(int S) { return (32 + S - 1) / S; }               // steps per chunk: the fewest with TS * S >= 32
 typedef const __attribute__((address_space(1))) void* gptr_t;          // operands of __builtin_amdgcn_global_load_lds
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -83,10 +87,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //    not).  Round 1 fetched per-row control chunks twice per stream: FETCH_SIZE 2.6x the algorithmic bytes.
 //  * the step loop is unrolled in groups (static register indices, rotated between groups), everything that
 //    depends on T is wave-uniform;
-//  * states leave through a wave-private LDS tile of TS steps x 64 rows as ALIGNED 16-byte stores: row r's window
-//    starts C_r floats before its chunk so that it begins on a 16-byte boundary of HBM; the C_r = (C_r + TS*S) mod 4
-//    trailing floats are carried to the next window, only the first 4 - C_r and the last < 4 floats of a row go
-//    out as dwords.  The pieces of a flush are dealt to the lanes densely (piece = j*64 + lane): no idle lanes;
+//  * states leave as WHOLE 128-byte lines.  Each row has a window in a wave-private LDS tile that starts on a line
+//    boundary of HBM (h_r floats before the row's first state); a chunk of TS steps appends TS*S >= 32 floats, the
+//    complete lines (1 or 2 per row and chunk) are stored by 8 lanes x 16 bytes each, the < 32 leftover floats
+//    move to the window front.  Only the first and the last line of a row (shared with its neighbours) are
+//    written in part.  Writing 112-byte runs instead (round 1, and the first version of this kernel) left every
+//    line open in L2 until the next flush 4 steps later: with ~3 MB of open lines per XCD they were evicted half
+//    written -- WRITE_SIZE 1.31x the algorithmic bytes and the L1 stalled on the write path 90 % of the time
+//    (profiles/r02_rollout_pmc_regs_kernel_112B_runs.txt);
 //  * nothing in the loop waits for memory: the stores are fire-and-forget (no load is outstanding after the
 //    prologue, so no s_waitcnt vmcnt is ever needed), LDS hazards are the wave's own in-order queue.
 // Bit-identical to the other roll-out kernels: the step functions are shared (rollout_step.h, no contraction).
@@ -94,19 +102,18 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define IRBFN_ROLL_MINW 3          // waves per SIMD the long-horizon instance is allocated for (100 control VGPRs)
 #endif
 template <int MODE, int TCH, int TS>
-__global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) void rollout_fwd_regs_kernel(const RollArgs a) {
+__global__ __launch_bounds__(64 * kRegsWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) void rollout_fwd_regs_kernel(const RollArgs a) {
   extern __shared__ float lds[];
   constexpr int S = ModeTraits<MODE>::S;
   constexpr int S0 = ModeTraits<MODE>::S0;
-  constexpr int CF = TS * S;                     // floats per full output chunk per row
-  constexpr int NP = CF / 4;                     // whole 16-byte pieces per row window and flush ((C + CF) >> 2, C < 4)
+  constexpr int CF = TS * S;                     // floats a full chunk appends to every row window
   constexpr int PITCH = roll_pitch(S, TS);       // odd: conflict-free per-lane row access
   constexpr int RPP = kRollRPP;                  // rows per input pass
   constexpr bool HAS_U = MODE != IRBFN_ROLLOUT_SPIRAL;
-  static_assert(CF % 4 == 0, "sliding-window flush: TS*S = 0 (mod 4) keeps the carry constant");
+  static_assert(CF >= 32 && CF <= 64, "a chunk completes at least one 128-byte line per row and at most two (+1 with the leftover)");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long b0 = ((long)blockIdx.x * kRollWaves + wave) * kWave;
+  const long b0 = ((long)blockIdx.x * kRegsWaves + wave) * kWave;
   if (b0 >= a.B) return;                         // whole wave out of range (no block-level barriers used)
   const long left = a.B - b0;
   const int nvalid = left < kWave ? (int)left : kWave;
@@ -183,42 +190,49 @@ __global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
     for (int i = 0; i < S; ++i) s[i] = q0[i];
   }
 
-  // ---- steps + sliding-window flush ------------------------------------------------------------------------
+  // ---- steps + whole-line flush ------------------------------------------------------------------------------
   float* gout = a.states + b0 * (long)T * S;     // tile base in HBM; row stride T*S
   const long rs = (long)T * S;
-  const int gC = (int)((reinterpret_cast<uintptr_t>(gout) >> 2) & 3);
-  auto carry_of = [&](int r) { return (gC + (int)((r * rs) & 3)) & 3; };   // floats of row r's window before its start
-  const int myC = carry_of(lane);
-  // pieces [0, npc_r) of every row window -> aligned float4 in HBM; nfl = floats the chunk added to each window
-  auto flush = [&](int t0, int nfl) {
+  const int g32 = (int)((reinterpret_cast<uintptr_t>(gout) >> 2) & 31);
+  auto head_of = [&](int r) { return (g32 + (int)((r * rs) & 31)) & 31; };   // floats between the line start and row r
+  const int myH = head_of(lane);
+  int fill = myH;                                // floats in my window (the first myH of them are not mine)
+  // lines [0, nl_r) of every row window -> HBM.  p0 = floats each row had produced before this chunk.
+  auto flush = [&](long p0, int nfl, bool last) {
+    const int sub = lane >> 3, k = lane & 7;     // 8 lanes per line
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int idx = j * kWave + lane;
-      const int r = idx / NP, part = idx - r * NP;
-      if (r < nvalid) {
-        const int C = carry_of(r);
-        const int npc = (C + nfl) >> 2;          // whole pieces available in this row's window
-        if (part < npc) {
-          const float* src = tile + r * PITCH + 4 * part;
-          float* dst = gout + r * rs + (long)t0 * S - C + 4 * part;     // 16-byte aligned
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll 1
+      for (int j = 0; j < kWave / 8; ++j) {
+        const int r = j * 8 + sub;
+        const int h = head_of(r);
+        const int f0 = (int)((h + p0) & 31);     // floats in row r's window before the chunk
+        const int tot = f0 + nfl;
+        const int nl = tot >> 5;                 // complete lines now in the window
+        const bool tail = last && l == nl && (tot & 31) > 0;             // the row's last, partial line
+        if (r < nvalid && (l < nl || tail)) {
+          const long q = (long)h + p0 - f0 + 32 * l;                     // line start, floats from the window origin W_r
+          const float* src = tile + r * PITCH + 32 * l + 4 * k;
+          float* dst = gout + r * rs - h + q + 4 * k;                    // 16-byte aligned
           const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-          if (t0 == 0 && part == 0 && C > 0) {   // the window starts before the row: only floats [C, 4) exist
-            if (C <= 1) dst[1] = v1;
-            if (C <= 2) dst[2] = v2;
-            dst[3] = v3;
-          } else {
+          int lo = (q == 0) ? h - 4 * k : 0;                             // first line of the row: floats [0, h) are not ours
+          int hi = tail ? (tot & 31) - 4 * k : 4;                        // last line: only (tot & 31) floats exist
+          if (lo <= 0 && hi >= 4) {
             *reinterpret_cast<float4*>(dst) = float4{v0, v1, v2, v3};
+          } else {
+            if (lo <= 0 && hi > 0) dst[0] = v0;
+            if (lo <= 1 && hi > 1) dst[1] = v1;
+            if (lo <= 2 && hi > 2) dst[2] = v2;
+            if (lo <= 3 && hi > 3) dst[3] = v3;
           }
         }
       }
     }
   };
-  int rem = myC;                                 // floats left in my window after the last flush
   // The step loop is ROLLED over groups of G steps (a straight-line 50-step body is ~70 KB of code: measured
   // instruction-fetch bound, 68 us per wave); inside a group the controls sit at static register indices, between
   // groups the control registers rotate down by G (2 (TCH - G) v_mov per group, ~5 % of a group's instructions).
-  constexpr int G = TCH < kRollGroup ? ((TCH + TS - 1) / TS) * TS : kRollGroup;
-  static_assert(G % TS == 0, "group = whole flush chunks");
+  constexpr int G = TCH < 2 * TS ? ((TCH + TS - 1) / TS) * TS : 2 * TS;
   const int ngroups = (T + G - 1) / G;
 #pragma unroll 1
   for (int gI = 0; gI < ngroups; ++gI) {
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
     for (int t0 = 0; t0 < G; t0 += TS) {
       if (tg + t0 < T) {                         // wave-uniform
         const int n = (T - tg - t0) < TS ? (T - tg - t0) : TS;
+        float* wr = mine + fill;
 #pragma unroll
         for (int tt = 0; tt < TS; ++tt) {
           if (t0 + tt < TCH && tt < n) {
@@ -236,17 +251,23 @@ __global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
             else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[t0 + tt], us[t0 + tt], a.dp);
             else spiral_step(s, coef, slen, tg + t0 + tt, T);
 #pragma unroll
-            for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
+            for (int i = 0; i < S; ++i) wr[tt * S + i] = s[i];
           }
         }
         lds_drain();
-        flush(tg + t0, n * S);
-        // carry the floats behind the last whole piece to the front of the window (full chunk: again myC of them)
-        const int tot = myC + n * S;
-        rem = tot & 3;
-        float c0 = mine[(tot & ~3) + 0], c1 = mine[(tot & ~3) + 1], c2 = mine[(tot & ~3) + 2];
+        flush((long)(tg + t0) * S, n * S, tg + t0 + n >= T);
+        // the floats behind the last complete line move to the window front
+        const int tot = fill + n * S;
+        const float* from = mine + (tot & ~31);
+        float keep[31];
+#pragma unroll
+        for (int i = 0; i < 31; ++i) keep[i] = from[i];
         lds_drain();
-        mine[0] = c0; mine[1] = c1; mine[2] = c2;
+        if (tot >= 32) {
+#pragma unroll
+          for (int i = 0; i < 31; ++i) mine[i] = keep[i];
+        }
+        fill = tot & 31;
       }
     }
     if constexpr (HAS_U && TCH > G) {
@@ -254,10 +275,214 @@ __global__ __launch_bounds__(64 * kRollWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
       for (int i = 0; i + G < TCH; ++i) { ua[i] = ua[i + G]; us[i] = us[i + G]; }
     }
   }
-  // epilogue: the < 4 floats left in my window go out as dwords
-  if (lane < nvalid) {
-    float* dst = gout + lane * rs + rs - rem;
-    for (int i = 0; i < rem; ++i) dst[i] = mine[i];
+}
+
+// K3p `rollout_fwd_pair_kernel<MODE, TCH, TS>`: TWO adjacent lanes per trajectory (32 trajectories per wave).
+// The step's two transcendental evaluations -- sincos of the heading, tan of the steering angle -- run in ONE
+// instruction stream (even lane: heading, odd lane: steering angle; TrigPair swaps the results by DPP), everything
+// else is evaluated redundantly by both lanes from the same operands: bit-identical to the one-lane step, ~40 %
+// fewer instructions per step, twice the waves.  What that buys:
+//  * small batches (the 32768-trajectory per-GPU share of config 4 is 512 one-lane waves for 1024 SIMDs): every
+//    SIMD gets a wave and the wave's serial chain is shorter;
+//  * large batches: half the trajectories in flight per resident wave, so half as many output rows are open at any
+//    time (DRAM page locality of the write stream) and a row window can hold TS = 10 steps: every flush writes
+//    2-3 whole lines per row;
+//  * the even lane keeps the acceleration knots, the odd lane the steering-rate knots (50 control VGPRs per lane
+//    instead of 100; each step broadcasts its pair by DPP).
+// Input / output machinery as in rollout_fwd_regs_kernel: whole-tile LDS-DMA prologue, row windows on 128-byte
+// line boundaries, whole-line stores, leftover compaction (split between the two lanes).
+struct TrigPair {
+  int odd;
+  static __device__ __forceinline__ float swap(float v) {           // quad_perm [1,0,3,2]: the partner lane's value
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  }
+  __device__ __forceinline__ void sincos_tan(float A, float B, bool small, float& sn, float& cs, float& tn) const {
+    (void)small;                                 // the range check of sincos_fast covers both angles
+    float s1, c1;
+    sincos_fast(odd ? B : A, s1, c1);
+    const float t1 = fdiv_fast(s1, c1);
+    const float s2 = swap(s1), c2 = swap(c1), t2 = swap(t1);
+    sn = odd ? s2 : s1;
+    cs = odd ? c2 : c1;
+    tn = odd ? t1 : t2;
+  }
+  __device__ __forceinline__ void sincos(float A, float& sn, float& cs) const { sincos_fast(A, sn, cs); }
+};
+
+#ifndef IRBFN_PAIR_FLOATS
+#define IRBFN_PAIR_FLOATS 70       // floats a chunk of the pair kernel appends to a row window (>= 32): S = 7 -> 10 steps
+#endif
+constexpr int pair_ts(int S) { return (IRBFN_PAIR_FLOATS + S - 1) / S; }
+#ifndef IRBFN_PAIR_MINW
+#define IRBFN_PAIR_MINW 4
+#endif
+constexpr int kPairWaves = 4;      // waves per workgroup
+constexpr int kPairRows = 32;      // trajectories per wave
+constexpr int pair_pitch(int S, int TS) { return (32 + TS * S) | 1; }      // leftover < 32 + one chunk + the odd lane's spare slot
+
+template <int MODE, int TCH, int TS>
+__global__ __launch_bounds__(64 * kPairWaves, IRBFN_PAIR_MINW) void rollout_fwd_pair_kernel(const RollArgs a) {
+  extern __shared__ float lds[];
+  constexpr int S = ModeTraits<MODE>::S;
+  constexpr int S0 = ModeTraits<MODE>::S0;
+  constexpr int SE = (S + 1) / 2;                // state components the even lane writes; the odd lane writes S - SE
+  constexpr int CF = TS * S;
+  constexpr int PITCH = pair_pitch(S, TS);
+  constexpr int RPP = kRollRPP;
+  constexpr int LMAX = ((31 + CF) >> 5) + 1;     // lines a row window can complete in one chunk, + the tail line
+  static_assert(MODE != IRBFN_ROLLOUT_SPIRAL, "the spiral has no control knots and no tan: one lane per path");
+  static_assert(CF >= 32, "a chunk completes at least one 128-byte line per row");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int odd = lane & 1, prow = lane >> 1;
+  const long b0 = ((long)blockIdx.x * kPairWaves + wave) * kPairRows;
+  if (b0 >= a.B) return;
+  const long left = a.B - b0;
+  const int nvalid = left < kPairRows ? (int)left : kPairRows;
+  const int T = a.T;
+  float* tile = lds + (size_t)wave * a.wlds;
+  float* mine = tile + prow * PITCH;
+  auto lds_drain = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- prologue: the row's state (both lanes) and ONE control stream per lane -> registers -------------------
+  float s[S], q0[S0], ctl[TCH];
+#pragma unroll
+  for (int t = 0; t < TCH; ++t) ctl[t] = 0.0f;
+  const bool dma = nvalid == kPairRows && a.dma_ok;
+  if (dma) {
+    const bool split = a.x0 != a.u - S0 || a.L0 != a.LU;
+#pragma unroll 1
+    for (int p = 0; p < kPairRows / RPP; ++p) {
+      const long r0 = b0 + (long)p * RPP;
+      int nf0 = RPP * (int)a.L0, nf1 = 0;
+      const float* src0 = a.x0 + r0 * a.L0;
+      const float* src1 = nullptr;
+      if (split) { nf1 = RPP * (int)a.LU; src1 = a.u + r0 * a.LU; }
+      for (int v = lane * 4; v < nf0; v += 256)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src0 + v), (lptr_t)(tile + (v - lane * 4)), 16, 0, 0);
+      for (int v = lane * 4; v < nf1; v += 256)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src1 + v), (lptr_t)(tile + nf0 + (v - lane * 4)), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if ((prow / RPP) == p) {
+        const float* rr = tile + (prow % RPP) * (int)a.L0;
+#pragma unroll
+        for (int i = 0; i < S0; ++i) q0[i] = rr[i];
+        const float* ur = (split ? tile + nf0 + (prow % RPP) * (int)a.LU : rr + S0) + (odd ? T : 0);
+#pragma unroll
+        for (int t = 0; t < TCH; ++t) ctl[t] = ur[t];   // slots t >= T are never used (an LDS read past the tile is harmless)
+      }
+      lds_drain();
+    }
+  } else {
+    const long bb = b0 + (prow < nvalid ? prow : nvalid - 1);
+    const float* row = a.x0 + bb * a.L0;
+    const float* urow = a.u + bb * a.LU + (odd ? T : 0);
+#pragma unroll
+    for (int i = 0; i < S0; ++i) q0[i] = row[i];
+#pragma unroll
+    for (int t = 0; t < TCH; ++t)
+      if (t < T) ctl[t] = urow[t];
+  }
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
+    s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
+    s[3] = clipf(q0[0], 0.0f, 7.0f);             // train_nmpc.py:319
+  } else {
+#pragma unroll
+    for (int i = 0; i < S; ++i) s[i] = q0[i];
+  }
+
+  // ---- steps + whole-line flush ------------------------------------------------------------------------------
+  float* gout = a.states + b0 * (long)T * S;
+  const long rs = (long)T * S;
+  const int g32 = (int)((reinterpret_cast<uintptr_t>(gout) >> 2) & 31);
+  auto head_of = [&](int r) { return (g32 + (int)((r * rs) & 31)) & 31; };
+  int fill = head_of(prow);
+  const TrigPair trig{odd};
+  auto flush = [&](long p0, int nfl, bool last) {
+    const int sub = lane >> 3, k = lane & 7;     // 8 lanes per line, 8 rows per instruction
+#pragma unroll 1
+    for (int j = 0; j < kPairRows / 8; ++j) {
+      const int r = j * 8 + sub;
+      const int h = head_of(r);
+      const int f0 = (int)((h + p0) & 31);       // floats in row r's window before the chunk
+      const int tot = f0 + nfl;
+      const int nl = tot >> 5;
+      const long q0l = (long)h + p0 - f0;        // first line of the window, floats from the window origin
+      const float* src = tile + r * PITCH + 4 * k;
+      float* dst = gout + r * rs - h + q0l + 4 * k;
+      if (r < nvalid) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          const bool tail = last && l == nl && (tot & 31) > 0;
+          if (l < nl || tail) {
+            const float v0 = src[32 * l], v1 = src[32 * l + 1], v2 = src[32 * l + 2], v3 = src[32 * l + 3];
+            const int lo = (q0l == 0 && l == 0) ? h - 4 * k : 0;       // the row's first line: floats [0, h) are not ours
+            const int hi = tail ? (tot & 31) - 4 * k : 4;              // the row's last line: (tot & 31) floats exist
+            float* d = dst + 32 * l;
+            if (lo <= 0 && hi >= 4) {
+#if IRBFN_ROLL_NT
+              __builtin_nontemporal_store(f4v{v0, v1, v2, v3}, reinterpret_cast<f4v*>(d));
+#else
+              *reinterpret_cast<float4*>(d) = float4{v0, v1, v2, v3};
+#endif
+            } else {
+              if (lo <= 0 && hi > 0) d[0] = v0;
+              if (lo <= 1 && hi > 1) d[1] = v1;
+              if (lo <= 2 && hi > 2) d[2] = v2;
+              if (lo <= 3 && hi > 3) d[3] = v3;
+            }
+          }
+        }
+      }
+    }
+  };
+  const int nchunks = (T + TS - 1) / TS;
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    const int tc = c * TS;
+    const int n = (T - tc) < TS ? (T - tc) : TS;
+    float* wr = mine + fill + (odd ? SE : 0);
+#pragma unroll
+    for (int tt = 0; tt < TS; ++tt) {
+      if (tt < TCH && tt < n) {                  // wave-uniform
+        const int cv = __builtin_bit_cast(int, ctl[tt]);
+        const float ua = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(cv, 0xA0, 0xF, 0xF, true));   // even lane's knot
+        const float us = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(cv, 0xF5, 0xF, 0xF, true));   // odd lane's knot
+        if constexpr (MODE == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua, us, a.dp, trig);
+        else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua, us, a.dp, trig);
+        else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua, us, trig);
+        else frenet_step(s, ua, us, a.dp, trig);
+        // even lane: components [0, SE), odd lane: [SE, S) (+ one spare slot that the next step overwrites)
+#pragma unroll
+        for (int i = 0; i < SE; ++i) {
+          float ev = s[i], od = s[(SE + i) < S ? SE + i : S - 1];
+          asm volatile("" : "+v"(ev), "+v"(od));             // two plain values: ONE v_cndmask (not an indexed select chain)
+          wr[tt * S + i] = odd ? od : ev;
+        }
+      }
+    }
+    lds_drain();
+    flush((long)tc * S, n * S, tc + n >= T);
+    // the floats behind the last complete line move to the window front (each lane moves every other one)
+    const int tot = fill + n * S;
+    const float* from = mine + (tot & ~31) + odd;
+    float keep[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keep[i] = from[2 * i];
+    lds_drain();
+    if (tot >= 32) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[2 * i + odd] = keep[i];
+    }
+    fill = tot & 31;
+    if constexpr (TCH > TS) {
+#pragma unroll
+      for (int i = 0; i + TS < TCH; ++i) ctl[i] = ctl[i + TS];
+    }
   }
 }
 
@@ -426,18 +651,37 @@ __global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(co
   }
 }
 
-#ifndef IRBFN_ROLL_TS
-#define IRBFN_ROLL_TS 4            // steps per flush of the regs kernel (TS * S = 0 mod 4)
-#endif
 constexpr int kRollTchLong = 50, kRollTchShort = 8;    // compiled unroll depths: T <= 8 (the reference's 5), T <= 50
 
 template <int MODE>
 static int launch_mode(const RollArgs& a0, hipStream_t s) {
   constexpr int S = ModeTraits<MODE>::S;
-  constexpr int TS = (MODE == IRBFN_ROLLOUT_SPIRAL && (IRBFN_ROLL_TS & 1)) ? IRBFN_ROLL_TS + 1 : IRBFN_ROLL_TS;
+  constexpr int TS = roll_ts(S);
   RollArgs a = a0;
   const long waves = (a.B + kWave - 1) / kWave;
   const long grid = (waves + kRollWaves - 1) / kRollWaves;
+  const long rgrid = (waves + kRegsWaves - 1) / kRegsWaves;
+  if constexpr (MODE != IRBFN_ROLLOUT_SPIRAL) {
+    if (a.T <= kRollTchLong && a.T > kRollTchShort) {
+      // K3p: two lanes per trajectory
+      constexpr int PTS = pair_ts(S);
+      const bool split = a.x0 != a.u - ModeTraits<MODE>::S0 || a.L0 != a.LU;
+      long w = (long)kPairRows * pair_pitch(S, PTS);
+      const long in_floats = (long)kRollRPP * (a.L0 + (split ? a.LU : 0));
+      if (in_floats > w) w = in_floats;
+      a.wlds = (int)((w + 3) & ~3L);
+      a.dma_ok = ((reinterpret_cast<uintptr_t>(a.x0) | reinterpret_cast<uintptr_t>(a.u)) & 15) == 0 ||
+                 (!split && (reinterpret_cast<uintptr_t>(a.x0) & 15) == 0);
+      const size_t lds = (size_t)kPairWaves * a.wlds * sizeof(float);
+      if (lds <= 64 * 1024) {
+        const long pw = (a.B + kPairRows - 1) / kPairRows;
+        hipLaunchKernelGGL((rollout_fwd_pair_kernel<MODE, kRollTchLong, PTS>), dim3((unsigned)((pw + kPairWaves - 1) / kPairWaves)),
+                           dim3(kWave * kPairWaves), lds, s, a);
+        IRBFN_HIP_CHECK(hipGetLastError());
+        return IRBFN_OK;
+      }
+    }
+  }
   if (a.T <= kRollTchLong) {
     // K3: controls in registers, whole-tile LDS-DMA input, fire-and-forget aligned stores
     const bool has_u = MODE != IRBFN_ROLLOUT_SPIRAL;
@@ -448,13 +692,13 @@ static int launch_mode(const RollArgs& a0, hipStream_t s) {
     a.wlds = (int)((w + 3) & ~3L);
     a.dma_ok = ((reinterpret_cast<uintptr_t>(a.x0) | reinterpret_cast<uintptr_t>(a.u)) & 15) == 0 ||
                (!split && (reinterpret_cast<uintptr_t>(a.x0) & 15) == 0);
-    const size_t lds = (size_t)kRollWaves * a.wlds * sizeof(float);
+    const size_t lds = (size_t)kRegsWaves * a.wlds * sizeof(float);
     if (lds <= 64 * 1024) {
       if (a.T <= kRollTchShort)
-        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchShort, TS>), dim3((unsigned)grid), dim3(kWave * kRollWaves),
+        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchShort, TS>), dim3((unsigned)rgrid), dim3(kWave * kRegsWaves),
                            lds, s, a);
       else
-        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchLong, TS>), dim3((unsigned)grid), dim3(kWave * kRollWaves),
+        hipLaunchKernelGGL((rollout_fwd_regs_kernel<MODE, kRollTchLong, TS>), dim3((unsigned)rgrid), dim3(kWave * kRegsWaves),
                            lds, s, a);
       IRBFN_HIP_CHECK(hipGetLastError());
       return IRBFN_OK;

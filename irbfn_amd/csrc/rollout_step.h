@@ -92,10 +92,22 @@ __device__ __forceinline__ float clipf(float v, float lo, float hi) {
   return v != v ? v : m;
 }
 
+// How a step gets its trigonometry: sincos(A) of the heading-like angle and tan(B) of the (clipped) steering angle.
+// TrigDirect: this lane evaluates both (one lane per trajectory).  TrigPair (rollout.hip): two adjacent lanes share
+// a trajectory, the even lane evaluates sincos(A), the odd lane sincos(B) and the quotient, results swap by DPP --
+// ONE polynomial evaluation per step instead of two, same values bit for bit.
+struct TrigDirect {
+  __device__ __forceinline__ void sincos_tan(float A, float B, bool small, float& sn, float& cs, float& tn) const {
+    sincos_fast(A, sn, cs);
+    tn = tan_clipped(B, small);
+  }
+  __device__ __forceinline__ void sincos(float A, float& sn, float& cs) const { sincos_fast(A, sn, cs); }
+};
+
 // Single-track model, src/irbfn_mpc/dynamics.py:9-91.  SELECT=true: x + select(V>3, f, f_ks)*dt (:90);
 // SELECT=false: kinematic RHS only = dynamic_st_onestep_aux (:103-187).
-template <bool SELECT>
-__device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_in, const DynParams& dp) {
+template <bool SELECT, typename Trig = TrigDirect>
+__device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_in, const DynParams& dp, const Trig trig = Trig()) {
 #pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float g = 9.81f;                                 // dynamics.py:6
   const float mu = dp.p[0], m = dp.p[1], I = dp.p[2], lf = dp.p[3], lr = dp.p[4], C_Sf = dp.p[5],
@@ -109,7 +121,7 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
   float f0, f1, f4, f5, f6;
   if (SELECT && V > 3.0f) {                              // :49-76
     float sn, cs;
-    sincos_fast(PSI + BETA, sn, cs);
+    trig.sincos(PSI + BETA, sn, cs);
     f0 = V * cs;
     f1 = V * sn;
     f4 = PSI_DOT;
@@ -122,11 +134,11 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
               (C_Sr * glf * lr - C_Sf * glr * lf) * (PSI_DOT / V)) -
          PSI_DOT;
   } else {                                               // :78-88
-    float sn, cs;
-    sincos_fast(PSI, sn, cs);
+    float sn, cs, tn;
+    trig.sincos_tan(PSI, DELTA, s_max < 4194304.0f, sn, cs, tn);
     f0 = V * cs;
     f1 = V * sn;
-    f4 = fdiv_fast(V, lr + lf) * tan_clipped(DELTA, s_max < 4194304.0f);
+    f4 = fdiv_fast(V, lr + lf) * tn;
     f5 = 0.0f;
     f6 = 0.0f;
   }
@@ -140,31 +152,34 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
 }
 
 // Inline kinematic bicycle of train_step_fullint, scripts/train_nmpc.py:329-347 / :356-374.
-__device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv) {
+template <typename Trig = TrigDirect>
+__device__ __forceinline__ void fullint_step(float (&s)[5], float a, float dv, const Trig trig = Trig()) {
 #pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float DT = 0.1f, WB = 0.33f, VMAX = 7.0f, VMIN = 0.0f, SMAX = 0.4189f;   // :307-311
-  float sn, cs;
-  sincos_fast(s[4], sn, cs);
+  const float dnew = clipf(s[2] + dv * DT, -SMAX, SMAX); // :362-363
+  float sn, cs, tn;
+  trig.sincos_tan(s[4], dnew, true, sn, cs, tn);
   s[0] = s[0] + s[3] * cs * DT;                          // :360
   s[1] = s[1] + s[3] * sn * DT;                          // :361
-  s[2] = clipf(s[2] + dv * DT, -SMAX, SMAX);             // :362-363
+  s[2] = dnew;
   s[3] = clipf(s[3] + a * DT, VMIN, VMAX);               // :364-365
-  s[4] = s[4] + fdiv_fast(s[3], WB) * tan_clipped(s[2], true) * DT;       // :366
+  s[4] = s[4] + fdiv_fast(s[3], WB) * tn * DT;           // :366
 }
 
 // Frenet model, low-speed RHS only, src/irbfn_mpc/dynamics.py:190-281 (:267-280).
-__device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_in, const DynParams& dp) {
+template <typename Trig = TrigDirect>
+__device__ __forceinline__ void frenet_step(float (&s)[8], float a_in, float dv_in, const DynParams& dp, const Trig trig = Trig()) {
 #pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
   const float LF = dp.p[3], LR = dp.p[4], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10],
               s_max = dp.p[11];
   const float ey = s[1], delta = clipf(s[2], -s_max, s_max), vx = s[3], epsi = s[6], cur = s[7];
   const float a = clipf(a_in, -a_max, a_max);            // :235
   const float dv = clipf(dv_in, -sv_max, sv_max);        // :236
-  float se, ce;
-  sincos_fast(epsi, se, ce);
+  float se, ce, td;
+  trig.sincos_tan(epsi, delta, s_max < 4194304.0f, se, ce, td);
   const float d0 = (vx * ce) / (1.0f - ey * cur);        // :268
   const float d1 = vx * se;                              // :269
-  const float d6 = fdiv_fast(vx * tan_clipped(delta, s_max < 4194304.0f), LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
+  const float d6 = fdiv_fast(vx * td, LR + LF) - cur * ((vx * ce) / (1.0f - cur * ey));  // :274-275
   s[0] = s[0] + d0 * dt;
   s[1] = s[1] + d1 * dt;
   s[2] = s[2] + dv * dt;
