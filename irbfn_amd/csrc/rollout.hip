@@ -328,7 +328,8 @@ __global__ __launch_bounds__(64 * kPairWaves, IRBFN_PAIR_MINW) void rollout_fwd_
   constexpr int SE = (S + 1) / 2;                // state components the even lane writes; the odd lane writes S - SE
   constexpr int CF = TS * S;
   constexpr int PITCH = pair_pitch(S, TS);
-  constexpr int RPP = kRollRPP;
+  constexpr int RPP = kRollRPP;                  // two 16-row input passes: one pass of 32 rows needs 13.7 KB of LDS per wave and
+                                                 // costs the third resident workgroup per CU (126 vs 107 us at B = 262144)
   constexpr int LMAX = ((31 + CF) >> 5) + 1;     // lines a row window can complete in one chunk, + the tail line
   static_assert(MODE != IRBFN_ROLLOUT_SPIRAL, "the spiral has no control knots and no tan: one lane per path");
   static_assert(CF >= 32, "a chunk completes at least one 128-byte line per row");
