@@ -5,19 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): RBF-net evals/s.  One "step" = one fused forward pass of the WCRBFNet
-(region gate + 4096 Gaussian centres + Dense) over one batch of 65 536 synthetic 7-D queries
-(BASELINE config 2), inputs and parameters resident in HBM.  Weak scaling: every rank processes its
-own 65 536-query shard; rank 0's parameters are broadcast once over RCCL before the timed region and
-there is no collective in the steady state.
+Metric (BASELINE.json): RBF-net evals/s (+ trajectories/s, fwd+bwd in ``extras``).  One "step" = one fused forward
+pass of the WCRBFNet (region gate + 4096 Gaussian centres + Dense) over one batch of 65 536 synthetic 7-D queries
+(BASELINE config 2), inputs and parameters resident in HBM.  Weak scaling: every rank processes its own
+65 536-query shard; rank 0's parameters are broadcast once over RCCL before the timed region and there is no
+collective in the steady state.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel, HIP-event timing on the launch stream) and ``cpu_baseline`` (the C
-restatement of the reference path, oracle/, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` (dominant kernel, HIP-event
+timing on the launch stream), ``cpu_baseline`` (the C restatement of the reference path, oracle/, timed on this
+box's host cores on a bounded sample; N = 1 only) and ``extras``.  At every N the extras hold the multi-GPU
+numbers the metric names, each timed like the headline (barrier + synchronize on both sides, MAX over ranks):
+config 4 STRONG-scaled (262 144 planning ticks split over the ranks: forward O = 100 + 50-step roll-out ->
+trajectories/s), config 3 weak-scaled forward + parameter VJP + ONE gradient all-reduce (evals/s), and the
+parameter broadcast.  At N = 1 the single-GPU kernel numbers (roll-outs, config 5 variants, ...) follow.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,8 +33,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak == dense f32-input MFMA peak
-PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak == dense f32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
+DTYPE = "f32 (Phi x W on f16 MFMA: hi/lo operand pairs, f32 accumulate)"
 
 
 def parse():
@@ -70,36 +77,41 @@ def dist_setup(n_gpus):
     return rank, world, local
 
 
+def _barrier(world):
+    import torch
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(v, world):
+    import torch
+    if world == 1:
+        return v
+    t = torch.tensor([v], dtype=torch.float64)
+    if torch.distributed.get_backend() == "nccl":
+        t = t.cuda()
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
 def timed_region(fn, steps, warmup, world):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks.
-    Also returns the HIP-event time of the same K launches on the launch stream."""
+    Also returns the HIP-event time of the same K launches on the launch stream (this rank)."""
     import torch
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
+    _barrier(world)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(steps):
         fn()
     e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
+    _barrier(world)
     wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    return wall, ev_ms
+    return _max_over_ranks(wall, world), e0.elapsed_time(e1)
 
 
 def main():
@@ -125,89 +137,136 @@ def main():
     x = torch.from_numpy(configs.synth_queries(idx, seed=1123 + rank)).cuda()
     torch.cuda.synchronize()
 
-    def step():
-        return net(x)
-
-    wall, ev_ms = timed_region(step, args.steps, args.warmup, world)
+    wall, ev_ms = timed_region(lambda: net(x), args.steps, args.warmup, world)
+    launch = net.last_launch()                   # the kernel of the timed region (the extras launch others)
     ms_per_step = wall / args.steps * 1e3
     value = B * world * args.steps / wall
 
-    if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
-    if world > 1:
-        # N > 1: the other ranks are gone after the timed region -- nothing below may issue a collective (the
-        # training-step extra all-reduces its gradients when a process group is up); CPU baseline and extras are
-        # reported at N = 1 only
-        args.no_cpu_baseline = True
-        args.no_extras = True
+    # every rank stays in the group until the end: the multi-GPU extras below are collective
+    extras = None
+    if not args.no_extras and idx == 2:
+        extras = scaling_extras(net, params, x, rank, world, configs, torch)
+        if world == 1:
+            extras.update(single_gpu_extras(net, params, x, configs, torch))
+            net.bind(params)
 
-    # ---- roofline of the dominant kernel (the fused forward): algorithmic work / event time
-    kern_s = ev_ms / 1e3 / args.steps
-    flops = B * N * (3 * D + 2 + 2 * O)                          # SURVEY 8(d): per pair 3D + 2 + 2O
+    if rank == 0:
+        roofline = forward_roofline(launch, B, N, D, O, ev_ms / 1e3 / args.steps)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(net, card, params, x, B, args.cpu_sample)
+        line = {
+            "metric": "RBF-net evals/s (B queries x N centres), forward", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config {idx}: {N} centres, d={D}, O={O}, batch={B} per GPU, "
+                                   f"{card['basis_func']} RBF forward (gate + RBF + Dense fused)",
+                       "centres": N, "in_features": D, "out_features": O, "batch_per_gpu": B,
+                       "global_batch": B * world, "basis": card["basis_func"], "parallelism": f"dp{world} (query shards)"},
+            "pair_evals_per_s": value * N,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if extras:
+            line["extras"] = extras
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        _barrier(world)
+        torch.distributed.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_fingerprint(names=("rbf_forward_f16.hip", "f16_split.h", "rbf_forward.h", "rbf_forward.hip")) -> str:
+    """Hash of the sources the headline kernel is built from: profiles/*_traffic.json is only trusted for the
+    code it was measured on (tools/measure_traffic.py stamps it)."""
+    h = hashlib.sha1()
+    for n in names:
+        with open(os.path.join(ROOT, "irbfn_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def forward_roofline(launch, B, N, D, O, kern_s):
+    """Roofline object of the fused forward: algorithmic work / HIP-event time per launch."""
+    flops = B * N * (3 * D + 2 + 2 * O)                          # per pair 3D + 2 + 2O
     abytes = 4 * (B * D + N * D + N + N * O + O + B * O)         # every tensor touched once
-    launch = net.last_launch()
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):                      # measured by rocprofv3 PMC passes of this same command
+    traffic, traffic_src = None, "none measured for this build (run tools/measure_traffic.py on the GPU box)"
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tpath):
         rec = json.load(open(tpath)).get(launch["kernel"])
-        if rec:
-            traffic, traffic_src = rec["bytes"], "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, per launch)"
-    roofline = {
+        if rec and rec.get("fingerprint") == kernel_fingerprint() and rec.get("grid") == launch["grid"]:
+            traffic = rec["bytes"]
+            traffic_src = ("profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+                           "command, per launch; source fingerprint and launch geometry match this build")
+        elif rec:
+            traffic_src = "profiles/r02_traffic.json is stale (kernel sources or launch geometry changed since it was measured)"
+    # the kernel's work by execution unit: the Phi x W products run on the f16 matrix cores as 3 f16 products per
+    # f32 product (ph*wh, pl*wh, ph*wl), the outputs padded to one 16-wide tile; the rest is f32 VALU + 1 transcendental
+    valu_flops = B * N * (3 * D + 2)
+    mfma_flops = 2.0 * B * N * 16 * 3
+    return {
         "bound": "mfma", "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
         "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
         "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
-        "note": "priced against the fp32 peak 157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak): distances, basis and the operand splits run on the f32 VALU, the centre x weight reduction on the f16 matrix cores with hi/lo operand pairs (float32-equivalent result, same error as the all-f32 kernel); VALU/transcendental-bound (2400 flop/B), not HBM-bound; transcendental count = B*N",
+        "note": "algorithmic f32 flops (SURVEY 8d: B*N*(3D+2+2O), transcendental count B*N) over the fp32 peak 157.3 "
+                "TFLOP/s (fp32 vector == dense f32-input MFMA peak).  The kernel is VALU/transcendental-issue bound "
+                "(2400 flop/B), not HBM-bound; `by_unit` prices the two pipes it runs on separately",
+        "by_unit": {
+            "valu_f32": {"flops": valu_flops, "tflops": valu_flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS,
+                         "frac": valu_flops / kern_s / 1e12 / PEAK_FP32_TFLOPS,
+                         "what": "distances + basis argument (3D+2 per pair) on the f32 VALU; + B*N transcendentals and "
+                                 "the hi/lo operand split (3.5 VALU instructions per pair, no algorithmic flops)"},
+            "mfma_f16": {"flops": mfma_flops, "tflops": mfma_flops / kern_s / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
+                         "frac": mfma_flops / kern_s / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                         "what": "issued f16 MFMA flops: 3 products x 16-wide output tile (O = 10 padded) per pair"}},
         "hbm": {"achieved": abytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": abytes / kern_s / 1e9 / PEAK_HBM_GBS},
     }
 
-    # ---- CPU baseline: C restatement of the reference path (oracle/), bounded sample, same box
-    cpu = None
-    if not args.no_cpu_baseline:
-        from oracle import c_oracle as co          # checker / baseline leg only
-        ns = min(args.cpu_sample, B)
-        co.set_num_threads(available_cores())
-        xs = x[:ns].cpu().numpy()
-        co.wcrbf_forward(card, params_np(params), xs[:4096], np.float32)      # warm-up (thread pool)
-        dts = []
-        for _ in range(5):                         # ~10-30 core-seconds of CPU work in total
+
+def cpu_baseline(net, card, params, x, B, sample):
+    """C/OpenMP restatement of the reference path (oracle/), bounded sample, same box (kind = "port": the
+    reference itself is JAX and cannot run here), + torch-CPU broadcast form."""
+    import torch
+    from oracle import c_oracle as co          # checker / baseline leg only
+    ns = min(sample, B)
+    co.set_num_threads(available_cores())
+    xs = x[:ns].cpu().numpy()
+    pn = params_np(params)
+    co.wcrbf_forward(card, pn, xs[:4096], np.float32)      # warm-up (thread pool)
+    dts = []
+    for _ in range(5):                         # ~10-30 core-seconds of CPU work in total
+        t0 = time.perf_counter()
+        ref = co.wcrbf_forward(card, pn, xs, np.float32)
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[2]
+    got = net(x[:ns]).cpu().numpy()
+    ref64 = co.wcrbf_forward(card, pn, xs[:1024], np.float64)
+    out = {"value": ns / dt, "unit": "evals/s", "cores": co.num_threads(), "kind": "port",
+           "sample": f"{ns} of the {B} queries of the same workload x 5 repeats (median), float32, OpenMP C "
+                     f"restatement of the reference path (oracle/irbfn_oracle.c), {dt:.3f} s wall per repeat "
+                     f"(~{5 * dt * co.num_threads():.0f} core-seconds of CPU work in total)",
+           "parity_rel_err_vs_f64": float(np.abs(got[:1024] - ref64).max() / np.abs(ref64).max()),
+           "parity_rel_err_vs_cpu_f32": float(np.abs(got - ref).max() / np.abs(ref).max())}
+    # XLA-like vectorised leg: torch-CPU float32, the explicit broadcast of flax_rbf.py:275-283 chunked over B
+    try:
+        from oracle import irbfn_oracle as orc
+        torch.set_num_threads(co.num_threads())
+        nt = min(ns, 8192)
+        xt = torch.from_numpy(xs[:nt])
+        pt = {"params": {g: {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()} for g, d in pn["params"].items()}}
+        with torch.no_grad():
+            orc.wcrbfnet_apply(card, pt, xt[:1024])
             t0 = time.perf_counter()
-            ref = co.wcrbf_forward(card, params_np(params), xs, np.float32)
-            dts.append(time.perf_counter() - t0)
-        dt = sorted(dts)[2]
-        got = net(x[:ns]).cpu().numpy()
-        ref64 = co.wcrbf_forward(card, params_np(params), xs[:1024], np.float64)
-        cpu = {"value": ns / dt, "unit": "evals/s", "cores": co.num_threads(), "kind": "port",
-               "sample": f"{ns} of the {B} queries of the same workload x 5 repeats (median), float32, OpenMP C "
-                         f"restatement of the reference path (oracle/irbfn_oracle.c), {dt:.3f} s wall per repeat "
-                         f"(~{5 * dt * co.num_threads():.0f} core-seconds of CPU work in total)",
-               "parity_rel_err_vs_f64": float(np.abs(got[:1024] - ref64).max() / np.abs(ref64).max()),
-               "parity_rel_err_vs_cpu_f32": float(np.abs(got - ref).max() / np.abs(ref).max())}
-
-    extras = None
-    if not args.no_extras and idx == 2:
-        extras = run_extras(net, params, x, configs, torch)
-
-    line = {
-        "metric": "RBF-net evals/s (B queries x N centres), forward", "value": value, "unit": "evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"BASELINE config {idx}: {N} centres, d={D}, O={O}, batch={B} per GPU, "
-                               f"{card['basis_func']} RBF forward (gate + RBF + Dense fused)",
-                   "centres": N, "in_features": D, "out_features": O, "batch_per_gpu": B,
-                   "global_batch": B * world, "basis": card["basis_func"], "parallelism": f"dp{world} (query shards)"},
-        "pair_evals_per_s": value * N,
-        "roofline": roofline, "cpu_baseline": cpu,
-    }
-    if extras:
-        line["extras"] = extras
-    print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+            for i in range(0, nt, 1024):
+                orc.wcrbfnet_apply(card, pt, xt[i:i + 1024])
+            dtt = time.perf_counter() - t0
+        out["torch_cpu_broadcast_form"] = {"value": nt / dtt, "unit": "evals/s", "cores": co.num_threads(),
+                                           "sample": f"{nt} queries, torch-CPU float32, chunks of 1024"}
+    except Exception as e:                      # the secondary leg must never sink the line
+        out["torch_cpu_broadcast_form"] = {"error": repr(e)[:200]}
+    return out
 
 
 def available_cores() -> int:
@@ -249,63 +308,115 @@ def _time(fn, reps, torch):
     return e0.elapsed_time(e1) / 1e3 / reps
 
 
-def run_extras(net, params, x, configs, torch):
-    """Secondary numbers (outside the timed region): fwd+VJP (cfg-3), stand-alone roll-out and fused
-    planning tick (per-GPU share of cfg-4)."""
-    from irbfn_amd import _lib, dynamics
+# ---------------------------------------------------------------------------------------------------------------
+def scaling_extras(net, params, x, rank, world, configs, torch):
+    """The multi-GPU numbers BASELINE.json's metric names, measured at EVERY N (all ranks take part):
+    broadcast of the parameters, config 4 strong-scaled planning ticks, config 3 weak-scaled fwd + VJP + all-reduce."""
+    from irbfn_amd import _lib, distributed
     from irbfn_amd.model import WCRBFNet
     from irbfn_amd.planner import plan_batch
     out = {}
+    # --- parameter broadcast (RCCL over xGMI at N > 1): the one collective of the forward path, at upload time
+    card4 = configs.model_card(4)
+    net4 = WCRBFNet.from_config(card4)
+    p4_host = configs.synth_params(4) if rank == 0 else None
+    distributed.broadcast_params(net4, p4_host, src=0)            # warm-up (communicator set-up)
+    _barrier(world)
+    t0 = time.perf_counter()
+    p4 = distributed.broadcast_params(net4, p4_host, src=0)
+    _barrier(world)
+    out["broadcast_params_cfg4"] = {"ms": _max_over_ranks(time.perf_counter() - t0, world) * 1e3,
+                                    "bytes": 4 * distributed.flat_param_count(net4),
+                                    "what": "host pytree -> flat device buffer -> ONE broadcast -> views (includes the H2D copy on rank 0)"}
+    net4.bind(p4)
+    # --- config 4, STRONG scaling: 262144 (start, goal) pairs split over the ranks; one tick = forward (4096
+    #     centres, O = 100) + 50-step kinematic single-track roll-out; no collective in the steady state
+    Bt = configs.batch_size(4)
+    lo, hi = distributed.shard_range(Bt, rank, world)
+    x4 = torch.from_numpy(configs.synth_queries(4, B=Bt)[lo:hi]).cuda()
+    s0 = torch.from_numpy(configs.initial_state_from_query(x4.cpu().numpy())).cuda()
+    steps4 = 20 if world > 1 else 10
+    tick = lambda: plan_batch(net4, p4, x4, s0, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS, return_controls=False)
+    wall, _ = timed_region(tick, steps4, 3, world)
+    out["cfg4_plan_tick_strong"] = {"traj_per_s": Bt * steps4 / wall, "ms_per_tick": wall / steps4 * 1e3,
+                                    "global_batch": Bt, "batch_per_gpu": hi - lo, "scaling": "strong", "steps": steps4,
+                                    "what": "forward O=100 (f16-MFMA wide kernel) + 50-step ST-kinematic roll-out per rank; "
+                                            "barrier + synchronize on both sides, max over ranks"}
+    del x4, s0
+    # --- config 3, WEAK scaling: forward + parameter VJP on each rank's 65536-query shard + ONE all-reduce of the
+    #     flat gradient buffer (0.3 MB)
     B = x.shape[0]
+    g = torch.from_numpy(configs.synth_cotangent(3, seed=2123 + rank)).cuda()
+    steps3 = 20
+
+    def fwd_bwd():
+        net(x)
+        return distributed.allreduce_grads(net, net.vjp(params, x, g))
+    wall, _ = timed_region(fwd_bwd, steps3, 3, world)
+    out["cfg3_fwd_vjp_allreduce_weak"] = {"evals_per_s": B * world * steps3 / wall, "ms_per_step": wall / steps3 * 1e3,
+                                          "batch_per_gpu": B, "global_batch": B * world, "scaling": "weak", "steps": steps3,
+                                          "what": "fused forward + parameter VJP (centres, widths, weights, bias) + one "
+                                                  "all-reduce(sum) of the flat gradient buffer (identity at N = 1)"}
+    return out
+
+
+def single_gpu_extras(net, params, x, configs, torch):
+    """Secondary single-GPU kernel numbers (outside the timed region)."""
+    from irbfn_amd import _lib, distributed, dynamics, train
+    from irbfn_amd.model import WCRBFNet
+    out = {}
+    B = x.shape[0]
+    N, D, O = 4096, 7, 10
+    pairs2 = float(B) * N
+    # the all-float32 VALU kernel on the headline workload (the kernel the f16-MFMA one replaced)
+    net.set_options(fwd_kernel=_lib.FWD_K1)
+    t = _time(lambda: net(x), 50, torch)
+    out["cfg2_fp32_valu_K1"] = {"us": t * 1e6, "evals_per_s": B / t, "kernel": net.last_launch()["kernel"],
+                                "fp32_tflops": pairs2 * (3 * D + 2 + 2 * O) / t / 1e12,
+                                "frac_of_fp32_peak": pairs2 * (3 * D + 2 + 2 * O) / t / 1e12 / PEAK_FP32_TFLOPS}
+    net.set_options(fwd_kernel=_lib.FWD_AUTO)
     g = torch.from_numpy(configs.synth_cotangent(3)).cuda()
     t = _time(lambda: (net(x), net.vjp(params, x, g)), 20, torch)
     out["cfg3_fwd_plus_vjp"] = {"evals_per_s": B / t, "ms": t * 1e3, "batch": B}
     # full training step (scripts/train_nmpc.py:258-300): forward + loss/seeds + VJP + clip/Adam, on device
-    from irbfn_amd import train
     state = train.TrainState.create(net, configs.synth_params(3), lr=1e-3, max_grad_norm=1.0)
     yt = torch.from_numpy(configs.synth_cotangent(3)).cuda()
     t = _time(lambda: train.train_step_oneint(state, x, yt, configs.DYN_PARAMS), 20, torch)
     out["cfg3_train_step_oneint"] = {"evals_per_s": B / t, "ms": t * 1e3, "batch": B,
                                      "what": "fwd + loss seeds + param VJP + clip_by_global_norm + adam, no host sync"}
     net.bind(params)
-    # roll-out: 32768 trajectories (cfg-4 per-GPU share), T = 50, kinematic single track
-    Bt, T = 32768, 50
-    st0 = configs.initial_state_from_query(x[:Bt].cpu().numpy())
-    u = np.random.default_rng(5).normal(0, 2.0, size=(Bt, 2 * T)).astype(np.float32)
-    xu = torch.from_numpy(np.hstack([st0, u])).cuda()
-    t = _time(lambda: dynamics.integrate_st_ks_mult(xu, configs.DYN_PARAMS), 50, torch)
-    rbytes = 4 * Bt * (7 + 2 * T + T * 7)
-    out["rollout_st_ks_T50"] = {"traj_per_s": Bt / t, "us": t * 1e6, "batch": Bt,
-                                "hbm_GBs": rbytes / t / 1e9, "hbm_frac": rbytes / t / 1e9 / PEAK_HBM_GBS,
-                                "algorithmic_bytes": rbytes,
-                                "note": "per-GPU share of cfg-4: 512 waves on 1024 SIMDs -> bound by one wave's serial "
-                                        "latency (50 dependent steps), not by HBM; see the whole-batch entry"}
-    # the whole cfg-4 batch on ONE GPU: the size at which the roll-out is actually HBM-bound
-    Bw = 262144
-    xw = configs.synth_queries(4, B=Bw)
-    stw = configs.initial_state_from_query(xw)
-    uw = np.random.default_rng(6).normal(0, 2.0, size=(Bw, 2 * T)).astype(np.float32)
-    xuw = torch.from_numpy(np.hstack([stw, uw])).cuda()
-    t = _time(lambda: dynamics.integrate_st_ks_mult(xuw, configs.DYN_PARAMS), 20, torch)
-    wbytes = 4 * Bw * (7 + 2 * T + T * 7)
-    out["rollout_st_ks_T50_whole_cfg4_batch"] = {"traj_per_s": Bw / t, "us": t * 1e6, "batch": Bw,
-                                                 "hbm_GBs": wbytes / t / 1e9, "hbm_frac": wbytes / t / 1e9 / PEAK_HBM_GBS,
-                                                 "algorithmic_bytes": wbytes}
-    del xuw
-    # fused planning tick, cfg-4 per-GPU share: 4096 centres, O = 100, B = 32768
+    # roll-out alone (the HBM-bound kernel): T = 50, kinematic single track; per-GPU share and whole cfg-4 batch
+    T = 50
+    for key, Bt, reps in (("rollout_st_ks_T50_per_gpu_share", 32768, 50), ("rollout_st_ks_T50_whole_cfg4_batch", 262144, 20)):
+        xq = configs.synth_queries(4, B=Bt)
+        st0 = configs.initial_state_from_query(xq)
+        u = np.random.default_rng(5).normal(0, 2.0, size=(Bt, 2 * T)).astype(np.float32)
+        xu = torch.from_numpy(np.hstack([st0, u])).cuda()
+        states = dynamics.integrate_st_ks_mult(xu, configs.DYN_PARAMS)
+        t = _time(lambda: dynamics.integrate_st_ks_mult(xu, configs.DYN_PARAMS), reps, torch)
+        rbytes = 4 * Bt * (7 + 2 * T + T * 7)
+        out[key] = {"traj_per_s": Bt / t, "us": t * 1e6, "batch": Bt, "algorithmic_bytes": rbytes,
+                    "roofline": {"bound": "hbm", "achieved": rbytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": rbytes / t / 1e9 / PEAK_HBM_GBS},
+                    "kernel": "rollout_fwd_pair_kernel<ST_KS> (2 lanes per trajectory, whole-line non-temporal stores)"}
+        del xu, states
+    # config 4 forward alone at the per-GPU share, by execution unit
     card4 = configs.model_card(4)
     net4 = WCRBFNet.from_config(card4)
-    from irbfn_amd import distributed
     p4 = distributed.params_to_device(configs.synth_params(4))
-    x4 = x[:Bt].contiguous()
-    s0 = torch.from_numpy(st0).cuda()
     net4.bind(p4)
-    t = _time(lambda: plan_batch(net4, p4, x4, s0, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS,
-                                 return_controls=False), 10, torch)
-    out["cfg4_fused_plan_tick"] = {"traj_per_s": Bt / t, "ms": t * 1e3, "batch": Bt,
-                                   "tflops": Bt * 4096 * (3 * 7 + 2 + 200) / t / 1e12}
+    x4 = torch.from_numpy(configs.synth_queries(4, B=32768)).cuda()
+    t = _time(lambda: net4(x4), 20, torch)
+    pairs4 = 32768.0 * 4096
+    out["cfg4_forward_O100_per_gpu_share"] = {
+        "us": t * 1e6, "evals_per_s": 32768 / t, "kernel": net4.last_launch()["kernel"],
+        "valu_f32": {"tflops": pairs4 * 23 / t / 1e12, "frac": pairs4 * 23 / t / 1e12 / PEAK_FP32_TFLOPS},
+        "mfma_f16": {"tflops": pairs4 * 2 * 112 * 3 / t / 1e12, "frac": pairs4 * 2 * 112 * 3 / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                     "what": "issued f16 MFMA flops: 3 products x 7 column tiles of 16 (O = 100 padded to 112)"},
+        "algorithmic_fp32_tflops": pairs4 * (3 * 7 + 2 + 200) / t / 1e12}
+    del x4
     # BASELINE config 5: 16384-centre inverse-multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs the reduction
-    # "cast as MFMA GEMM": K1h at float32 accuracy (hi/lo f16 operand split) and with plain f16 operands
+    # "cast as MFMA GEMM": K1h at float32 accuracy (hi/lo f16 operand pairs) and with plain f16 operands
     card5 = configs.model_card(5)
     net5 = WCRBFNet.from_config(card5)
     p5 = distributed.params_to_device(configs.synth_params(5))
@@ -315,31 +426,27 @@ def run_extras(net, params, x, configs, torch):
     pairs = float(B5) * N5
     res5 = {"batch": B5, "centres": N5, "basis": card5["basis_func"]}
     ref_out = None
-    for key, env in (("fp32_valu_K1", {"IRBFN_FWD_F16": "0"}),
-                     ("f16x3_mfma_K1h_fp32_accurate", {"IRBFN_FWD_F16": "1", "IRBFN_FWD_F16_TERMS": "3"}),
-                     ("f16_mfma_K1h_reduced_precision", {"IRBFN_FWD_F16": "1", "IRBFN_FWD_F16_TERMS": "1"})):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            t = _time(lambda: net5(x5), 3, torch)
-            o5 = net5(x5)[:4096].float().cpu().numpy()
-            kern = net5.last_launch()["kernel"]
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+    for key, opts in (("fp32_valu_K1", {"fwd_kernel": _lib.FWD_K1}),
+                      ("f16x3_mfma_K1h_fp32_accurate", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 3}),
+                      ("f16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 1})):
+        net5.set_options(**opts)
+        t = _time(lambda: net5(x5), 3, torch)
+        o5 = net5(x5)[:4096].float().cpu().numpy()
+        kern = net5.last_launch()["kernel"]
+        net5.set_options(fwd_kernel=_lib.FWD_AUTO, fwd_f16_terms=3)
         if ref_out is None:
             ref_out = o5
         entry = {"ms": t * 1e3, "evals_per_s": B5 / t, "kernel": kern,
-                 "fp32_equiv_tflops": pairs * (3 * 7 + 2 + 2 * 10) / t / 1e12,
+                 "algorithmic_fp32_tflops": pairs * (3 * 7 + 2 + 2 * 10) / t / 1e12,
+                 "valu_f32_frac": pairs * 23 / t / 1e12 / PEAK_FP32_TFLOPS,
                  "max_rel_dev_vs_fp32_kernel": float(np.abs(o5 - ref_out).max() / np.abs(ref_out).max())}
         if "K1h" in key:
-            # matrix-core share: MFMA instructions of 16 cycles per 16x16x32 tile product, over the kernel's SIMD time
             terms = 3 if "x3" in key else 1
-            mfma_cycles = pairs / (16 * 32) * terms * 16.0
-            entry["mfma_busy_frac"] = mfma_cycles / (t * 2.4e9 * 1024)
+            entry["mfma_f16"] = {"tflops": pairs * 2 * 16 * terms / t / 1e12,
+                                 "frac": pairs * 2 * 16 * terms / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                 "busy_frac": pairs / (16 * 32) * terms * 16.0 / (t * 2.4e9 * 1024),
+                                 "what": "matrix-core utilisation asked for by BASELINE config 5: issued f16 MFMA flops over "
+                                         "the dense f16 peak, and MFMA issue cycles (16 per 16x16x32 product) over SIMD time"}
         res5[key] = entry
     out["cfg5_imq_16384_centres"] = res5
     return out

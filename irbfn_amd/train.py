@@ -30,7 +30,11 @@ class TrainState:
         self.flat = flat
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
-        self.g = torch.zeros_like(flat)
+        # gradients + two trailing slots (loss * B_local, B_local) so that ONE all-reduce yields the global-batch
+        # mean gradient and loss whatever the shard sizes are (distributed.shard_range hands out sizes that
+        # differ by one row)
+        self.gbuf = torch.zeros(flat.numel() + 2, dtype=torch.float32, device=flat.device)
+        self.g = self.gbuf[:flat.numel()]
         self.step = torch.zeros(1, dtype=torch.int32, device=flat.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.partials = torch.zeros(_lib.load().irbfn_train_loss_partials(), dtype=torch.float32, device=flat.device)
@@ -48,17 +52,26 @@ class TrainState:
 
 
 def _backward_and_update(state: TrainState, x, gy, torch, lib):
+    """VJP -> [all-reduce] -> clip + Adam.  Returns the loss of the (global) batch, a 1-element device tensor."""
     state.net.vjp(state.params, x, gy, out=state.grads)
+    loss = state.loss.clone()
     if distributed.is_dist() and torch.distributed.get_world_size() > 1:
-        # every rank normalised its seeds by its local batch: global-mean gradient = mean of the partials
-        torch.distributed.all_reduce(state.g, op=torch.distributed.ReduceOp.SUM)
-        state.g.div_(torch.distributed.get_world_size())
+        # every rank normalised its seeds and its loss by its LOCAL batch: weight both by B_local, sum over the
+        # ranks in one all-reduce of the flat buffer, divide by the global batch (exact for unequal shards)
+        n, b_local = state.flat.numel(), float(x.shape[0])
+        state.g.mul_(b_local)
+        state.gbuf[n:n + 1].copy_(state.loss * b_local)
+        state.gbuf[n + 1:].fill_(b_local)
+        torch.distributed.all_reduce(state.gbuf, op=torch.distributed.ReduceOp.SUM)
+        state.g.div_(state.gbuf[n + 1])
+        loss = (state.gbuf[n:n + 1] / state.gbuf[n + 1]).clone()
     st = lib.irbfn_adam_clip_step(_ptr(state.flat), _ptr(state.g), _ptr(state.m), _ptr(state.v), state.flat.numel(),
                                   _ptr(state.step), state.lr, state.b1, state.b2, state.eps, state.max_grad_norm,
                                   _ptr(state.partials), _stream_ptr(torch))
     _lib.check(st, "irbfn_adam_clip_step")
     # the parameter leaves were updated in place behind torch's back: re-bind on the next apply
     state.net._bound_fp.pop(torch.cuda.current_device(), None)
+    return loss
 
 
 def train_step_oneint(state: TrainState, x, y, dyn_params, clip_tie: float = 0.5) -> Tuple[TrainState, "object"]:
@@ -75,9 +88,7 @@ def train_step_oneint(state: TrainState, x, y, dyn_params, clip_tie: float = 0.5
     st = lib.irbfn_train_seeds_oneint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy), _ptr(state.loss),
                                       _ptr(state.partials), B, xd.shape[1], O, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_oneint")
-    loss = state.loss.clone()
-    _backward_and_update(state, xd, gy, torch, lib)
-    return state, loss
+    return state, _backward_and_update(state, xd, gy, torch, lib)
 
 
 def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[TrainState, "object"]:
@@ -93,9 +104,7 @@ def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[
     st = lib.irbfn_train_seeds_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), float(clip_tie), _ptr(gy), _ptr(state.loss),
                                        _ptr(state.partials), B, xd.shape[1], O // 2, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_fullint")
-    loss = state.loss.clone()
-    _backward_and_update(state, xd, gy, torch, lib)
-    return state, loss
+    return state, _backward_and_update(state, xd, gy, torch, lib)
 
 
 def train_epoch(state: TrainState, table, batch_size: int, only_onestep: bool = False, dyn_params=None):

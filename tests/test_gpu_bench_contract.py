@@ -26,11 +26,13 @@ def test_single_gpu_line(gpu):
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2
-    assert j["unit"] == "evals/s" and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert j["unit"] == "evals/s" and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"].startswith("f32")
     assert "workload" in j["config"] and "model" not in j["config"]
     rf = j["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
+    assert rf["kernel"].startswith("rbf_fwd_f16mfma<") and "TERMS=3" in rf["kernel"]      # the product path, full precision
+    assert {"valu_f32", "mfma_f16"} <= set(rf["by_unit"]) and rf["by_unit"]["mfma_f16"]["frac"] < 1.0
     cb = j["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
     assert cb["parity_rel_err_vs_f64"] < 1e-5
@@ -42,6 +44,13 @@ def test_two_ranks_share_the_gpu_over_gloo(gpu):
                         "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5",
                         "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)                      # ONE line (rank 0), no extras / CPU baseline at N > 1
+    j = _json_line(r.stdout)                      # ONE line (rank 0); the CPU baseline is an N = 1 item
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"]
-    assert j["cpu_baseline"] is None and "extras" not in j and j["value"] > 0
+    assert j["cpu_baseline"] is None and j["value"] > 0
+    # the N-rank numbers the metric names: strong-scaled trajectories/s, weak-scaled fwd + VJP + all-reduce, broadcast
+    ex = j["extras"]
+    tick, fb = ex["cfg4_plan_tick_strong"], ex["cfg3_fwd_vjp_allreduce_weak"]
+    assert tick["global_batch"] == 262144 and tick["batch_per_gpu"] == 131072 and tick["traj_per_s"] > 0
+    assert fb["global_batch"] == 2 * fb["batch_per_gpu"] and fb["evals_per_s"] > 0
+    assert ex["broadcast_params_cfg4"]["bytes"] > 1_000_000 and ex["broadcast_params_cfg4"]["ms"] > 0
+    assert "cfg5_imq_16384_centres" not in ex     # single-GPU kernel numbers are reported at N = 1 only
