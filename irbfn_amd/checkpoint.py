@@ -6,8 +6,15 @@
   a msgpack map ``{step, params, opt_state}`` whose ndarrays are ext type 1 =
   ``msgpack((shape, dtype_name, raw_bytes))``.  Decoded with plain ``msgpack`` -- nothing is unpickled.
 
-``restore_checkpoint`` returns the parameter pytree ``WCRBFNet.apply`` takes; ``save_checkpoint``
-writes a file the reference's ``restore_checkpoint`` can read back (same container, float32 leaves).
+``restore_checkpoint`` returns the parameter pytree ``WCRBFNet.apply`` takes.  ``save_checkpoint`` writes the
+tree the reference's ``checkpoints.restore_checkpoint(ckpt_dir, target=state)`` expects (irbfn_planner.py:88,
+eval_irbfn_dnmpc.py:54): ``step`` as a 0-d integer array and ``opt_state`` with the structure of
+``optax.chain(clip_by_global_norm, adam)`` (scripts/train_nmpc.py:231-233) --
+``{'0': {}, '1': {'0': {'count', 'mu': {'params': ...}, 'nu': {'params': ...}}, '1': {}}}`` -- flax restores a
+tuple state from a dict with one entry per element and refuses any other length.  The structure is the one
+decoded from the reference's own files (the older runs hold the bare-adam form ``{'0': {count, mu, nu}, '1': {}}``;
+``restore_opt_state`` reads both).  flax / optax are not importable here: the round trip through the reference's
+loader itself is **parity unpinned**; tests/test_checkpoint_cpu.py compares key structures with a reference file.
 """
 from __future__ import annotations
 
@@ -41,7 +48,7 @@ def _ext_hook(code, data):
 def _default(obj):
     import msgpack
     if isinstance(obj, np.ndarray):
-        a = np.ascontiguousarray(obj)
+        a = np.asarray(obj, order="C")              # (ascontiguousarray would turn a 0-d array into shape (1,))
         return msgpack.ExtType(1, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True))
     if isinstance(obj, (np.integer,)):
         return int(obj)
@@ -87,8 +94,7 @@ def restore_checkpoint(ckpt: str) -> Tuple[dict, int]:
     return params, int(tree.get("step", 0))
 
 
-def save_checkpoint(ckpt_dir: str, params: dict, step: int, prefix: str = "checkpoint_") -> str:
-    import msgpack
+def _host_tree(params: dict) -> dict:
     p = params["params"] if "params" in params else params
 
     def host(a):
@@ -97,7 +103,33 @@ def save_checkpoint(ckpt_dir: str, params: dict, step: int, prefix: str = "check
     for name in ("linear_pre1", "linear_pre2", "linear"):
         if name in p:
             inner[name] = {"kernel": host(p[name]["kernel"]), "bias": host(p[name]["bias"])}
-    tree = {"step": int(step), "params": {"params": inner}, "opt_state": {}}
+    return inner
+
+
+def restore_opt_state(ckpt: str):
+    """Adam moments of a checkpoint: (mu pytree, nu pytree, count) or None.  Reads the chain(clip, adam) form the
+    reference writes today and the bare-adam form of its older runs."""
+    path = latest_checkpoint(ckpt) if os.path.isdir(ckpt) else ckpt
+    opt = load_flax_msgpack(path).get("opt_state") or {}
+    for cand in (opt.get("1", {}).get("0") if isinstance(opt.get("1"), dict) else None, opt.get("0")):
+        if isinstance(cand, dict) and {"count", "mu", "nu"} <= set(cand):
+            return {"params": cand["mu"]["params"]}, {"params": cand["nu"]["params"]}, int(cand["count"])
+    return None
+
+
+def save_checkpoint(ckpt_dir: str, params: dict, step: int, prefix: str = "checkpoint_", opt_state=None) -> str:
+    """opt_state: None (fresh optimiser: zero moments, count 0) or (mu pytree, nu pytree, count) -- e.g.
+    ``train.TrainState.opt_state()``."""
+    import msgpack
+    inner = _host_tree(params)
+    if opt_state is None:
+        zeros = {g: {n: np.zeros_like(a) for n, a in d.items()} for g, d in inner.items()}
+        mu, nu, count = zeros, {g: {n: a.copy() for n, a in d.items()} for g, d in zeros.items()}, 0
+    else:
+        mu, nu, count = _host_tree(opt_state[0]), _host_tree(opt_state[1]), int(opt_state[2])
+    adam = {"count": np.asarray(count, np.int32), "mu": {"params": mu}, "nu": {"params": nu}}
+    tree = {"step": np.asarray(int(step), np.int64), "params": {"params": inner},
+            "opt_state": {"0": {}, "1": {"0": adam, "1": {}}}}
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, f"{prefix}{step}")
     with open(path, "wb") as f:

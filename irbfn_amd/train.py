@@ -45,10 +45,21 @@ class TrainState:
 
     @classmethod
     def create(cls, net: WCRBFNet, params: dict, lr: float = 1e-3, max_grad_norm: float = 1.0,
-               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> "TrainState":
+               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8, opt_state=None) -> "TrainState":
+        """opt_state: (mu pytree, nu pytree, count) to resume (``checkpoint.restore_opt_state``)."""
         _lib.require_gpu()
         flat = distributed.flatten_params(distributed.params_to_device(params)).clone()
-        return cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+        st = cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+        if opt_state is not None:
+            st.m.copy_(distributed.flatten_params(distributed.params_to_device(opt_state[0])))
+            st.v.copy_(distributed.flatten_params(distributed.params_to_device(opt_state[1])))
+            st.step.fill_(int(opt_state[2]))
+        return st
+
+    def opt_state(self):
+        """(mu pytree, nu pytree, count): what ``checkpoint.save_checkpoint(..., opt_state=)`` stores (one host sync)."""
+        return (distributed.unflatten_params(self.net, self.m), distributed.unflatten_params(self.net, self.v),
+                int(self.step.item()))
 
 
 def _backward_and_update(state: TrainState, x, gy, torch, lib):

@@ -79,6 +79,29 @@ def wcrbf_forward(cfg, params, x, dtype=np.float32):
     return out
 
 
+def wcrbf_vjp(cfg, params, x, gout, dtype=np.float64):
+    """Parameter VJP for full-size batches (C twin of irbfn_oracle.wcrbfnet_vjp): -> gradient pytree."""
+    lib = load()
+    p = params["params"] if "params" in params else params
+    c = np.ascontiguousarray(p["rbf_list"]["centers"], dtype)
+    ls = np.ascontiguousarray(p["rbf_list"]["log_sigs"], dtype)
+    W = np.ascontiguousarray(p["linear"]["kernel"], dtype)
+    x = np.ascontiguousarray(x, dtype)
+    g = np.ascontiguousarray(gout, dtype)
+    ns, mr, lo, hi, delta, dr, nr = gate_tables(cfg, dtype)
+    R, K, D = c.shape
+    O = W.shape[1]
+    gc, gl, gW, gb = np.empty_like(c), np.empty_like(ls), np.empty_like(W), np.empty((O,), dtype)
+    fn = lib.oracle_wcrbf_vjp_f32 if dtype == np.float32 else lib.oracle_wcrbf_vjp_f64
+    fn.restype = C.c_int
+    rc = fn(_p(x), _p(g), _p(c), _p(ls), _p(W), _p(lo), _p(hi), _p(delta), _p(dr), C.c_int(nr), C.c_int(mr), C.c_int(ns),
+            C.c_int(BASIS_ENUM[cfg["basis_func"]]), C.c_long(x.shape[0]), C.c_int(D), C.c_int(R), C.c_int(K), C.c_int(O),
+            _p(gc), _p(gl), _p(gW), _p(gb))
+    if rc != 0:
+        raise ValueError(f"hand VJP not defined for basis {cfg['basis_func']}")
+    return {"params": {"rbf_list": {"centers": gc, "log_sigs": gl}, "linear": {"kernel": gW, "bias": gb}}}
+
+
 def _roll(name, dtype, xu, p, T, S, extra=()):
     lib = load()
     xu = np.ascontiguousarray(xu, dtype)

@@ -101,6 +101,90 @@ void FN(oracle_wcrbf_forward)(const REAL* x, const REAL* centers, const REAL* lo
   }
 }
 
+/* a-5: parameter VJP of a-1..a-4 (what jax.value_and_grad returns at scripts/train_nmpc.py:297-298), the C twin
+ * of oracle/irbfn_oracle.py::wcrbfnet_vjp for full-size batches: cotangent gout[B,O] ->
+ * g_centers[R,K,D], g_log_sigs[R,K], g_W[K,O], g_bias[O].  d^2-only bases (gaussian family, inverse_quadratic,
+ * inverse_multiquadric, multiquadric, quadratic); returns -1 otherwise.  OpenMP over centres (a thread owns its
+ * k range: no reduction across threads), queries streamed in chunks that stay in cache. */
+int FN(oracle_wcrbf_vjp)(const REAL* x, const REAL* gout, const REAL* centers, const REAL* log_sigs, const REAL* W,
+                         const REAL* lo_tab, const REAL* hi_tab, const REAL* delta, const int* dim_ranges,
+                         int n_ranges, int max_ranges, int nsplit, int basis, long B, int D, int R, int K, int O,
+                         REAL* g_centers, REAL* g_log_sigs, REAL* g_W, REAL* g_bias) {
+  if (!(basis == 0 || basis == 1 || basis == 2 || basis == 3 || basis == 5 || basis == 6 || basis == 7)) return -1;
+  const REAL one = (REAL)1;
+  REAL* gamma = (REAL*)malloc(sizeof(REAL) * (size_t)B * (size_t)R);
+#pragma omp parallel
+  {
+    REAL* gd = (REAL*)malloc(sizeof(REAL) * (size_t)(nsplit > 0 ? nsplit : 1) * (size_t)max_ranges);
+#pragma omp for schedule(static)
+    for (long b = 0; b < B; ++b) {                   /* model.py:42-95 */
+      const REAL* xb = x + b * D;
+      for (int d = 0; d < nsplit; ++d)
+        for (int j = 0; j < max_ranges; ++j) {
+          REAL ld = xb[d] - lo_tab[d * max_ranges + j];
+          REAL ud = hi_tab[d * max_ranges + j] - xb[d];
+          gd[d * max_ranges + j] = ((R_TANH(delta[d] * ld) + 1) / 2) * ((R_TANH(delta[d] * ud) + 1) / 2);
+        }
+      for (int r = 0; r < R; ++r) {
+        REAL gm = (REAL)0;
+        if (r < n_ranges) {
+          gm = gd[0 * max_ranges + dim_ranges[r * nsplit + 0]];
+          for (int j = 1; j < nsplit; ++j) gm = gm * gd[j * max_ranges + dim_ranges[r * nsplit + j]];
+        }
+        gamma[b * R + r] = gm;
+      }
+    }
+    free(gd);
+#pragma omp for schedule(static)
+    for (int o = 0; o < O; ++o) {                    /* d bias = sum_b g */
+      REAL acc = (REAL)0;
+      for (long b = 0; b < B; ++b) acc += gout[b * O + o];
+      g_bias[o] = acc;
+    }
+#pragma omp for schedule(dynamic, 8)
+    for (int k = 0; k < K; ++k) {
+      for (int o = 0; o < O; ++o) g_W[(size_t)k * O + o] = (REAL)0;
+      for (int r = 0; r < R; ++r) {
+        g_log_sigs[(size_t)r * K + k] = (REAL)0;
+        for (int j = 0; j < D; ++j) g_centers[((size_t)r * K + k) * D + j] = (REAL)0;
+      }
+      for (long b = 0; b < B; ++b) {
+        const REAL* xb = x + b * D;
+        const REAL* gb = gout + b * O;
+        REAL hbar = (REAL)0;                         /* hbar = g W^T */
+        for (int o = 0; o < O; ++o) hbar += gb[o] * W[(size_t)k * O + o];
+        REAL hk = (REAL)0;
+        for (int r = 0; r < R; ++r) {
+          const REAL gm = gamma[b * R + r];
+          const REAL* c = centers + ((size_t)r * K + k) * D;
+          const REAL s2 = R_EXP((REAL)-2 * log_sigs[(size_t)r * K + k]);
+          REAL r2 = (REAL)0;
+          for (int j = 0; j < D; ++j) { REAL df = xb[j] - c[j]; r2 += df * df; }
+          const REAL d2 = r2 * s2;
+          REAL phi, dphi;                            /* phi(d^2) and d phi / d(d^2) */
+          switch (basis) {
+            case 0: phi = R_EXP(-d2); dphi = -phi; break;
+            case 1: phi = R_EXP((REAL)-0.1 * d2); dphi = (REAL)-0.1 * phi; break;
+            case 2: phi = R_EXP((REAL)-0.01 * d2); dphi = (REAL)-0.01 * phi; break;
+            case 3: phi = one / (one + d2); dphi = -(phi * phi); break;
+            case 5: phi = d2; dphi = one; break;
+            case 6: phi = R_SQRT(one + d2); dphi = (REAL)0.5 / phi; break;
+            default: phi = one / R_SQRT(one + d2); dphi = (REAL)-0.5 * phi * phi * phi; break;
+          }
+          hk += gm * phi;
+          const REAL t = hbar * gm * dphi;
+          g_log_sigs[(size_t)r * K + k] += t * ((REAL)-2 * d2);
+          const REAL cf = t * s2 * (REAL)-2;
+          for (int j = 0; j < D; ++j) g_centers[((size_t)r * K + k) * D + j] += cf * (xb[j] - c[j]);
+        }
+        for (int o = 0; o < O; ++o) g_W[(size_t)k * O + o] += hk * gb[o];   /* d W = h^T g */
+      }
+    }
+  }
+  free(gamma);
+  return 0;
+}
+
 /* a-7: src/irbfn_mpc/dynamics.py:9-91 ; kinematic_only != 0 gives a-8 (:103-187) per step. */
 static inline void FN(st_step)(REAL* s, REAL accl_in, REAL sv_in, const REAL* p, int kinematic_only) {
   const REAL g = (REAL)9.81;

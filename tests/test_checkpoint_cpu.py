@@ -31,6 +31,41 @@ def test_roundtrip(tmp_path):
         checkpoint.restore_checkpoint(str(empty))
 
 
+def _keys(t):
+    return {k: _keys(v) for k, v in t.items()} if isinstance(t, dict) else None
+
+
+def test_written_tree_has_the_structure_the_reference_restores_into(tmp_path):
+    """flax restores `target=state` leaf by leaf: the written opt_state must have the key structure of
+    optax.chain(clip_by_global_norm, adam) -- as decoded (plain msgpack) from the reference's own newest run,
+    scripts/ckpts/dnmpc_1regions_newdata_oldintloss_nomirror_highk/checkpoint_999 -- and `step` must be an array."""
+    ref_opt = {"0": {}, "1": {"0": {"count": None, "mu": {"params": {"linear": {"bias": None, "kernel": None},
+                                                                     "rbf_list": {"centers": None, "log_sigs": None}}},
+                                    "nu": {"params": {"linear": {"bias": None, "kernel": None},
+                                                      "rbf_list": {"centers": None, "log_sigs": None}}}}, "1": {}}}
+    P = configs.synth_params(1)
+    rng = np.random.default_rng(0)
+    mu = {"params": {g: {n: rng.normal(size=a.shape).astype(np.float32) for n, a in d.items()} for g, d in P["params"].items()}}
+    nu = {"params": {g: {n: np.abs(rng.normal(size=a.shape)).astype(np.float32) for n, a in d.items()} for g, d in P["params"].items()}}
+    path = checkpoint.save_checkpoint(str(tmp_path), P, step=1234, opt_state=(mu, nu, 1234))
+    tree = checkpoint.load_flax_msgpack(path)
+    assert _keys(tree["opt_state"]) == ref_opt
+    assert isinstance(tree["step"], np.ndarray) and tree["step"].shape == () and int(tree["step"]) == 1234
+    assert tree["opt_state"]["1"]["0"]["count"].dtype == np.int32
+    mu2, nu2, count = checkpoint.restore_opt_state(path)
+    assert count == 1234
+    np.testing.assert_array_equal(mu2["params"]["linear"]["kernel"], mu["params"]["linear"]["kernel"])
+    np.testing.assert_array_equal(nu2["params"]["rbf_list"]["centers"], nu["params"]["rbf_list"]["centers"])
+    fresh = checkpoint.load_flax_msgpack(checkpoint.save_checkpoint(str(tmp_path / "f"), P, step=0))
+    assert _keys(fresh["opt_state"]) == ref_opt and not fresh["opt_state"]["1"]["0"]["mu"]["params"]["linear"]["kernel"].any()
+    if os.path.isdir(REF):                    # this container: compare with the reference's own file
+        ref = checkpoint.load_flax_msgpack(os.path.join(REF, "ckpts", "dnmpc_1regions_newdata_oldintloss_nomirror_highk", "checkpoint_999"))
+        assert _keys(ref["opt_state"]) == ref_opt and _keys(ref["params"]) == _keys(tree["params"])
+        assert isinstance(ref["step"], np.ndarray) and ref["step"].shape == ()
+        old = checkpoint.restore_opt_state(os.path.join(REF, "ckpts", "dnmpc_128regions"))      # bare-adam form of older runs
+        assert old is not None and old[0]["params"]["linear"]["kernel"].shape == (10, 10)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
 def test_reads_reference_checkpoint_and_card():
     run = "dnmpc_128regions"

@@ -229,3 +229,28 @@ def test_oneint_loss_value_and_grad_finite():
     lv = orc.train_oneint_loss(cfg, orc.cast_params(params, np.float64), x, y, dp)
     assert abs(float(loss) - float(lv)) < 1e-12 * max(1.0, abs(float(lv)))
     assert all(torch.isfinite(l.grad).all() for l in (tp["params"]["rbf_list"]["centers"], tp["params"]["linear"]["kernel"]))
+
+
+def test_c_vjp_matches_the_numpy_restatement():
+    """oracle_wcrbf_vjp (C, OpenMP -- used for the full-size GPU comparisons) == wcrbfnet_vjp (NumPy) on the gated
+    R = 128 / R = 12 checkpoints and on every basis class the hand VJP covers."""
+    from conftest import load_ckpt_fixture
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(0)
+    for run in ("dnmpc_128regions", "dnmpc_12regions_frenet_l1_bigdata"):
+        cfg, P, x, *_ = load_ckpt_fixture(run)
+        g = rng.normal(size=(x.shape[0], cfg["out_features"]))
+        a, b = co.wcrbf_vjp(cfg, P, x, g)["params"], orc.wcrbfnet_vjp(cfg, orc.cast_params(P, np.float64), x, g)["params"]
+        for grp, n in (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias")):
+            ref = np.asarray(b[grp][n])
+            assert np.abs(a[grp][n] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), (run, n)
+    for basis in ("gaussian_wide", "inverse_multiquadric", "multiquadric", "quadratic"):
+        cfg = dict(configs.model_card(1), basis_func=basis)
+        P, x = configs.synth_params(1), configs.synth_queries(1, B=200)
+        g = rng.normal(size=(200, cfg["out_features"]))
+        a, b = co.wcrbf_vjp(cfg, P, x, g)["params"], orc.wcrbfnet_vjp(cfg, orc.cast_params(P, np.float64), x, g)["params"]
+        for grp, n in (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel")):
+            ref = np.asarray(b[grp][n])
+            assert np.abs(a[grp][n] - ref).max() <= 1e-11 * np.abs(ref).max(), (basis, n)
+    with pytest.raises(ValueError):
+        co.wcrbf_vjp(dict(configs.model_card(1), basis_func="matern32"), P, x, g)
