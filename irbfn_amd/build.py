@@ -38,7 +38,7 @@ UNITS = [
     ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace
     ("rollout.hip", "rollout.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
-    ("rollout_vjp.hip", "rollout_vjp.o", []),
+    ("rollout_vjp.hip", "rollout_vjp.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
     ("train_step.hip", "train_step.o", []),
     ("mlp_head.hip", "mlp_head.o", []),
     ("planner_front.hip", "planner_front.o", []),

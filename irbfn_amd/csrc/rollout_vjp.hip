@@ -239,12 +239,366 @@ __global__ __launch_bounds__(64) void rollout_vjp_spiral(const RollVjpArgs a) {
   grow[4] = g_s;
 }
 
+// ---- K4: the same reverse sweeps with the memory machinery of the forward roll-out (T <= 50) ---------------------
+// The kernels above touch HBM through per-lane strided dwords (measured 0.5-0.9 TB/s at T = 50).  Here:
+//  * input rows: whole-tile LDS-DMA, the 2T controls of a trajectory live in registers (as in rollout.hip);
+//  * no [T][3][64] park: the forward pass keeps a CHECKPOINT of the few state components the adjoint needs every
+//    G = 10 steps (15 registers); the reverse pass re-runs one 10-step segment at a time into registers
+//    (exactly the forward's values: same step function) and sweeps it backwards;
+//  * the segment's seeds gstates[b, t0 .. t0+G, :] (G*S floats per row) are fetched as aligned 16-byte pieces by
+//    the whole wave into an LDS tile and read back per row;
+//  * the control gradients overwrite the controls IN PLACE in the registers -- the arrays rotate circularly by G
+//    per segment so that every access has a static register index and the gradients end in natural order -- and
+//    leave with the state cotangent as ONE contiguous tile through LDS (whole 128-byte lines, non-temporal).
+typedef const __attribute__((address_space(1))) void* vgptr_t;
+typedef __attribute__((address_space(3))) void* vlptr_t;
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+template <int MODE> struct VjpTraits;
+template <> struct VjpTraits<IRBFN_ROLLOUT_ST_KS> { static constexpr int S = 7, S0 = 7, NP = 3; };
+template <> struct VjpTraits<IRBFN_ROLLOUT_FULLINT> { static constexpr int S = 5, S0 = 1, NP = 3; };
+template <> struct VjpTraits<IRBFN_ROLLOUT_FRENET_LS> { static constexpr int S = 8, S0 = 8, NP = 4; };
+
+struct RollVjp2Args {
+  const float* __restrict__ x0u;      // [B][L]
+  const float* __restrict__ gstates;  // [B][T][S]
+  float* __restrict__ gx0u;           // [B][L]
+  long B;
+  int T, L, wlds, dma_ok;
+  float tie;
+  DynParams dp;
+};
+
+constexpr int kVjpWaves = 2, kVjpRPP = 16;
+constexpr int vjp_group(int TCH) { return TCH >= 10 ? 10 : TCH; }
+constexpr int vjp_pitch(int S, int G) { return (G * S + 6) | 1; }       // aligned superset of G*S floats, odd
+
+template <int MODE>
+__device__ __forceinline__ void vjp_park(const float* s, float* p) {
+  if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) { p[0] = s[1]; p[1] = s[2]; p[2] = s[3]; p[3] = s[6]; }
+  else { p[0] = s[2]; p[1] = s[3]; p[2] = s[4]; }
+}
+
+// one reverse step: lam already holds the seeds of this step's output state; returns d/d(a_t), d/d(sv_t)
+template <int MODE>
+__device__ __forceinline__ void vjp_back_step(const float* p, float a_in, float sv_in, float* lam, float cur, float tie,
+                                              const DynParams& dp, float& ga, float& gsv) {
+  if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) {
+    const float lf = dp.p[3], lr = dp.p[4], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10], s_max = dp.p[11], v_max = dp.p[12];
+    const float Lw = lr + lf;
+    const float d_raw = p[0], v_raw = p[1], psi = p[2];
+    const float DELTA = clipf(d_raw, -s_max, s_max), V = clipf(v_raw, -v_max, v_max);
+    const float md = clipgrad(d_raw, -s_max, s_max, tie), mv = clipgrad(v_raw, -v_max, v_max, tie);
+    const float ma = clipgrad(a_in, -a_max, a_max, tie), ms = clipgrad(sv_in, -sv_max, sv_max, tie);
+    float cp, sp, td;
+    TrigDirect().sincos_tan(psi, DELTA, s_max < 4194304.0f, sp, cp, td);
+    ga = ma * dt * lam[3];
+    gsv = ms * dt * lam[2];
+    const float l2 = lam[2] + md * lam[4] * (V / Lw) * (1.0f + td * td) * dt;
+    const float l3 = lam[3] + mv * dt * (lam[0] * cp + lam[1] * sp + lam[4] * td / Lw);
+    const float l4 = lam[4] + dt * V * (-lam[0] * sp + lam[1] * cp);
+    lam[2] = l2; lam[3] = l3; lam[4] = l4;
+  } else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
+    const float DT = 0.1f, WB = 0.33f, VMAX = 7.0f, VMIN = 0.0f, SMAX = 0.4189f;
+    const float d0 = p[0], v0 = p[1], psi = p[2];
+    const float dpre = d0 + sv_in * DT, vpre = v0 + a_in * DT;
+    const float d1 = clipf(dpre, -SMAX, SMAX), v1 = clipf(vpre, VMIN, VMAX);
+    const float md = clipgrad(dpre, -SMAX, SMAX, tie), mv = clipgrad(vpre, VMIN, VMAX, tie);
+    float cp, sp, td;
+    TrigDirect().sincos_tan(psi, d1, true, sp, cp, td);
+    const float Ld = lam[2] + lam[4] * (v1 / WB) * (1.0f + td * td) * DT;   // cotangent on delta'
+    const float Lv = lam[3] + lam[4] * td * DT / WB;                        // cotangent on v'
+    ga = mv * Lv * DT;
+    gsv = md * Ld * DT;
+    const float l2 = md * Ld;
+    const float l3 = mv * Lv + DT * (lam[0] * cp + lam[1] * sp);
+    const float l4 = lam[4] + DT * v0 * (-lam[0] * sp + lam[1] * cp);
+    lam[2] = l2; lam[3] = l3; lam[4] = l4;
+  } else {
+    const float LF = dp.p[3], LR = dp.p[4], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10], s_max = dp.p[11];
+    const float Lw = LR + LF;
+    const float ey = p[0], d_raw = p[1], vx = p[2], epsi = p[3];
+    const float dc = clipf(d_raw, -s_max, s_max);
+    const float md = clipgrad(d_raw, -s_max, s_max, tie);
+    const float ma = clipgrad(a_in, -a_max, a_max, tie), ms = clipgrad(sv_in, -sv_max, sv_max, tie);
+    float ce, se, td;
+    TrigDirect().sincos_tan(epsi, dc, s_max < 4194304.0f, se, ce, td);
+    const float den = 1.0f - ey * cur;
+    const float d0 = vx * ce / den;
+    const float A = lam[0] * dt - lam[6] * dt * cur;      // total cotangent on d0
+    ga = ma * dt * lam[3];
+    gsv = ms * dt * lam[2];
+    const float l1 = lam[1] + A * (vx * ce * cur / (den * den));
+    const float l2 = lam[2] + md * lam[6] * dt * vx * (1.0f + td * td) / Lw;
+    const float l3 = lam[3] + A * ce / den + lam[1] * dt * se + lam[6] * dt * td / Lw;
+    const float l6 = lam[6] + A * (-vx * se / den) + lam[1] * dt * vx * ce;
+    const float l7 = lam[7] + A * (vx * ce * ey / (den * den)) - lam[6] * dt * d0;
+    lam[1] = l1; lam[2] = l2; lam[3] = l3; lam[6] = l6; lam[7] = l7;
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void vjp_fwd_step(float* s, float a_in, float sv_in, const DynParams& dp) {
+  if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(*reinterpret_cast<float(*)[7]>(s), a_in, sv_in, dp);
+  else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(*reinterpret_cast<float(*)[5]>(s), a_in, sv_in);
+  else frenet_step(*reinterpret_cast<float(*)[8]>(s), a_in, sv_in, dp);
+}
+
+template <int MODE, int TCH>
+__global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(const RollVjp2Args a) {
+  extern __shared__ float lds[];
+  constexpr int S = VjpTraits<MODE>::S, S0 = VjpTraits<MODE>::S0, NP = VjpTraits<MODE>::NP;
+  constexpr int G = vjp_group(TCH), NG = TCH / G;
+  constexpr int PITCH = vjp_pitch(S, G);
+  constexpr int NPC = (G * S + 6) / 4;           // 16-byte pieces of a row's aligned seed chunk
+  constexpr int RPP = kVjpRPP;
+  static_assert(TCH % G == 0, "whole groups");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long b0 = ((long)blockIdx.x * kVjpWaves + wave) * kWave;
+  if (b0 >= a.B) return;
+  const long left = a.B - b0;
+  const int nvalid = left < kWave ? (int)left : kWave;
+  const int T = a.T, L = a.L;
+  float* tile = lds + (size_t)wave * a.wlds;
+  float* mine = tile + lane * PITCH;
+  auto lds_drain = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const bool dma = nvalid == kWave && a.dma_ok;
+
+  // ---- prologue: my row -> registers ---------------------------------------------------------------------------
+  float q0[S0], ua[TCH], us[TCH];
+#pragma unroll
+  for (int t = 0; t < TCH; ++t) { ua[t] = 0.0f; us[t] = 0.0f; }
+  if (dma) {
+#pragma unroll 1
+    for (int p = 0; p < kWave / RPP; ++p) {
+      const float* src = a.x0u + (b0 + (long)p * RPP) * L;
+      const int nf = RPP * L;
+      for (int v = lane * 4; v < nf; v += 256)
+        __builtin_amdgcn_global_load_lds((vgptr_t)(src + v), (vlptr_t)(tile + (v - lane * 4)), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if ((lane / RPP) == p) {
+        const float* rr = tile + (lane % RPP) * L;
+#pragma unroll
+        for (int i = 0; i < S0; ++i) q0[i] = rr[i];
+#pragma unroll
+        for (int t = 0; t < TCH; ++t) { ua[t] = rr[S0 + t]; us[t] = rr[S0 + T + t]; }     // slots t >= T are never used
+      }
+      lds_drain();
+    }
+  } else {
+    const float* row = a.x0u + (b0 + (lane < nvalid ? lane : nvalid - 1)) * L;
+#pragma unroll
+    for (int i = 0; i < S0; ++i) q0[i] = row[i];
+#pragma unroll
+    for (int t = 0; t < TCH; ++t)
+      if (t < T) { ua[t] = row[S0 + t]; us[t] = row[S0 + T + t]; }
+  }
+  float s[S];
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
+    s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
+    s[3] = clipf(q0[0], 0.0f, 7.0f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < S; ++i) s[i] = q0[i];
+  }
+  [[maybe_unused]] float cur = 0.0f;
+  if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) cur = s[7];
+
+  // ---- pass 1: forward, one checkpoint per group; the arrays (and the checkpoint list) rotate DOWN circularly:
+  //      static register indices inside the rolled loop, natural order after NG groups
+  float ck[NG][NP];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ck[g][i] = 0.0f;
+#pragma unroll 1
+  for (int gI = 0; gI < NG; ++gI) {
+    {
+      float pk[NP];
+      vjp_park<MODE>(s, pk);
+#pragma unroll
+      for (int g = 0; g + 1 < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) ck[g][i] = ck[g + 1][i];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ck[NG - 1][i] = pk[i];     // after the remaining rotations: group g at ck[g]
+    }
+#pragma unroll
+    for (int tt = 0; tt < G; ++tt)
+      if (gI * G + tt < T) vjp_fwd_step<MODE>(s, ua[tt], us[tt], a.dp);
+    if constexpr (NG > 1) {
+      float ta[G], ts[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) { ta[i] = ua[i]; ts[i] = us[i]; }
+#pragma unroll
+      for (int i = 0; i + G < TCH; ++i) { ua[i] = ua[i + G]; us[i] = us[i + G]; }
+#pragma unroll
+      for (int i = 0; i < G; ++i) { ua[TCH - G + i] = ta[i]; us[TCH - G + i] = ts[i]; }
+    }
+  }
+
+  // ---- pass 2: segments in reverse; the group's controls sit at [TCH - G, TCH) ---------------------------------
+  const float* gs_tile = a.gstates + b0 * (long)T * S;
+  const long rs = (long)T * S;
+  const int g4 = (int)((reinterpret_cast<uintptr_t>(gs_tile) >> 2) & 3);
+  float lam[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) lam[i] = 0.0f;
+#pragma unroll 1
+  for (int gI = NG - 1; gI >= 0; --gI) {
+    const int t0 = gI * G;
+    if (t0 < T) {                                // wave-uniform
+      const int n = (T - t0) < G ? (T - t0) : G;
+      // seeds of steps [t0, t0 + n) of every row -> LDS (aligned 16-byte pieces, the whole wave), or per-lane dwords
+      const int myC = (g4 + (int)((lane * rs + (long)t0 * S) & 3)) & 3;
+      if (dma) {
+        constexpr int NB = 5;                    // loads in flight per lane
+#pragma unroll 1
+        for (int j0 = 0; j0 < NPC; j0 += NB) {
+          vf4 v[NB];
+          int off[NB];
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj) {
+            const int idx = (j0 + jj) * kWave + lane;
+            const int r = idx / NPC, part = idx - r * NPC;
+            const int C = (g4 + (int)((r * rs + (long)t0 * S) & 3)) & 3;
+            off[jj] = (j0 + jj < NPC && 4 * part < C + n * S) ? r * PITCH + 4 * part : -1;
+            const float* src = gs_tile + r * rs + (long)t0 * S - C + 4 * part;      // 16-byte aligned, inside the tile
+            if (off[jj] >= 0) v[jj] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(src));
+          }
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj)
+            if (off[jj] >= 0) {
+              float* d = tile + off[jj];
+              d[0] = v[jj].x; d[1] = v[jj].y; d[2] = v[jj].z; d[3] = v[jj].w;
+            }
+        }
+      } else {
+        const float* src = gs_tile + (lane < nvalid ? lane : nvalid - 1) * rs + (long)t0 * S;
+        for (int i = 0; i < n * S; ++i) mine[myC + i] = src[i];
+      }
+      lds_drain();
+      // re-run the segment from its checkpoint: pre-step quantities of every step into registers
+      float ss[S], park[G][NP], pk[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) pk[i] = ck[NG - 1][i];
+#pragma unroll
+      for (int i = 0; i < S; ++i) ss[i] = 0.0f;
+      if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) { ss[1] = pk[0]; ss[2] = pk[1]; ss[3] = pk[2]; ss[6] = pk[3]; ss[7] = cur; }
+      else { ss[2] = pk[0]; ss[3] = pk[1]; ss[4] = pk[2]; }
+#pragma unroll
+      for (int tt = 0; tt < G; ++tt) {
+        vjp_park<MODE>(ss, park[tt]);
+        if (tt < n) vjp_fwd_step<MODE>(ss, ua[TCH - G + tt], us[TCH - G + tt], a.dp);
+      }
+#pragma unroll
+      for (int tt = G - 1; tt >= 0; --tt) {
+        if (tt < n) {
+#pragma unroll
+          for (int i = 0; i < S; ++i) lam[i] += mine[myC + tt * S + i];
+          float ga, gsv;
+          vjp_back_step<MODE>(park[tt], ua[TCH - G + tt], us[TCH - G + tt], lam, cur, a.tie, a.dp, ga, gsv);
+          ua[TCH - G + tt] = ga;                 // the control is dead from here on: its slot takes the gradient
+          us[TCH - G + tt] = gsv;
+        }
+      }
+      lds_drain();
+    }
+    if constexpr (NG > 1) {                      // rotate UP circularly: the next (earlier) group moves to [TCH - G, TCH)
+#pragma unroll
+      for (int g = NG - 1; g > 0; --g)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) ck[g][i] = ck[g - 1][i];
+      float ta[G], ts[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) { ta[i] = ua[TCH - G + i]; ts[i] = us[TCH - G + i]; }
+#pragma unroll
+      for (int i = TCH - 1; i >= G; --i) { ua[i] = ua[i - G]; us[i] = us[i - G]; }
+#pragma unroll
+      for (int i = 0; i < G; ++i) { ua[i] = ta[i]; us[i] = ts[i]; }
+    }
+  }
+  // cotangent of the initial state
+  float g0[S0];
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) g0[0] = clipgrad(q0[0], 0.0f, 7.0f, a.tie) * lam[3];
+  else {
+#pragma unroll
+    for (int i = 0; i < S0; ++i) g0[i] = lam[i];
+  }
+
+  // ---- epilogue: gradient rows -> HBM, RPP rows per pass as one contiguous block of whole lines -----------------
+  float* gout = a.gx0u + b0 * L;
+  if (dma) {
+#pragma unroll 1
+    for (int p = 0; p < kWave / RPP; ++p) {
+      if ((lane / RPP) == p) {
+        float* rr = tile + (lane % RPP) * L;
+#pragma unroll
+        for (int i = 0; i < S0; ++i) rr[i] = g0[i];
+#pragma unroll
+        for (int t = 0; t < TCH; ++t)
+          if (t < T) { rr[S0 + t] = ua[t]; rr[S0 + T + t] = us[t]; }
+      }
+      lds_drain();
+      float* dst = gout + (long)p * RPP * L;
+      const int nf = RPP * L;                    // multiple of 4 floats; dst is 16-byte aligned
+      for (int v = lane * 4; v < nf; v += 256) {
+        const vf4 val = *reinterpret_cast<const vf4*>(tile + v);
+        __builtin_nontemporal_store(val, reinterpret_cast<vf4*>(dst + v));
+      }
+      lds_drain();
+    }
+  } else if (lane < nvalid) {
+    float* grow = gout + (long)lane * L;
+#pragma unroll
+    for (int i = 0; i < S0; ++i) grow[i] = g0[i];
+#pragma unroll
+    for (int t = 0; t < TCH; ++t)
+      if (t < T) { grow[S0 + t] = ua[t]; grow[S0 + T + t] = us[t]; }
+  }
+}
+
+template <int MODE>
+static int launch_vjp_regs(const float* x0u, const DynParams& dp, const float* gstates, float* g_x0u, int64_t B, int T,
+                           float tie, hipStream_t s) {
+  constexpr int S = VjpTraits<MODE>::S;
+  RollVjp2Args a;
+  a.x0u = x0u; a.gstates = gstates; a.gx0u = g_x0u; a.B = (long)B; a.T = T; a.L = rollout_input_dim(MODE, T);
+  a.tie = tie; a.dp = dp;
+  const int TCH = T <= 8 ? 8 : 50;
+  const int G = vjp_group(TCH);
+  long w = (long)kWave * vjp_pitch(S, G);
+  if ((long)kVjpRPP * a.L > w) w = (long)kVjpRPP * a.L;
+  a.wlds = (int)((w + 3) & ~3L);
+  a.dma_ok = ((reinterpret_cast<uintptr_t>(x0u) | reinterpret_cast<uintptr_t>(gstates) | reinterpret_cast<uintptr_t>(g_x0u)) & 15) == 0;
+  const size_t lds = (size_t)kVjpWaves * a.wlds * sizeof(float);
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  const long waves = (B + kWave - 1) / kWave;
+  const dim3 grid((unsigned)((waves + kVjpWaves - 1) / kVjpWaves)), block(kWave * kVjpWaves);
+  if (TCH == 8) hipLaunchKernelGGL((rollout_vjp_regs_kernel<MODE, 8>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((rollout_vjp_regs_kernel<MODE, 50>), grid, block, lds, s, a);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
 int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const float* gstates,
                        float* g_x0u, int64_t B, int T, float clip_tie, hipStream_t s) {
   if (B == 0) return IRBFN_OK;
   RollVjpArgs a;
   a.x0u = x0u; a.gstates = gstates; a.gx0u = g_x0u; a.B = (long)B; a.T = T;
   a.L = rollout_input_dim(mode, T); a.tie = clip_tie; a.dp = dp;
+  if (T >= 1 && T <= 50) {                       // K4 with staged memory traffic (the kernels below: longer horizons)
+    int rc = IRBFN_ERR_UNSUPPORTED;
+    if (mode == IRBFN_ROLLOUT_ST_KS) rc = launch_vjp_regs<IRBFN_ROLLOUT_ST_KS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    else if (mode == IRBFN_ROLLOUT_FULLINT) rc = launch_vjp_regs<IRBFN_ROLLOUT_FULLINT>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    else if (mode == IRBFN_ROLLOUT_FRENET_LS) rc = launch_vjp_regs<IRBFN_ROLLOUT_FRENET_LS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
   int ns;
   switch (mode) {
     case IRBFN_ROLLOUT_ST_KS:
