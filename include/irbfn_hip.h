@@ -203,6 +203,13 @@ int irbfn_train_seeds_oneint(const float* x_dev, const float* y_pred_dev, const 
 int irbfn_train_seeds_fullint(const float* x_dev, const float* y_pred_dev, const float* y_dev, float clip_tie,
                               float* gy_dev, float* loss_dev, float* partials_dev, int64_t B, int D, int T,
                               void* stream);
+/* irbfn_train_seeds_frenet_fullint: loss_fn of the Frenet train_step_fullint (scripts/train_nmpc_frenet.py:394-421):
+ *   x [B,8] = [ey, delta, vx_car, vy_car, vx_goal, wz, epsi, curv], initial_state = x[:, [0,0,1,2,3,5,6,7]] (:398),
+ *   loss = mean|y_pred - y| + mean|integrate_frenet_mult([init, y_pred]) - integrate_frenet_mult([init, y])|, O = 2T,
+ *   T <= 16 (the reference: 5).  Writes gy = d loss / d y_pred [B,2T] and the scalar loss. */
+int irbfn_train_seeds_frenet_fullint(const float* x_dev, const float* y_pred_dev, const float* y_dev,
+                                     const float* dyn_params_host, float clip_tie, float* gy_dev, float* loss_dev,
+                                     float* partials_dev, int64_t B, int D, int T, void* stream);
 int irbfn_adam_clip_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n,
                          int* step_dev, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                          float* partials_dev, void* stream);
@@ -257,6 +264,14 @@ int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gam
  * reference).  Forward only. */
 int irbfn_mlp_head_forward(const float* h1_dev, const float* w2_dev, const float* b2_dev, const float* w3_dev,
                            const float* b3_dev, float* out_dev, int64_t B, int H1, int H2, int O, void* stream);
+
+/* VJP of that head (the reference trains the model: scripts/train_nmpc_frenet.py:339-421): gout [B,O] ->
+ * gh1 [B,H1] (cotangent of linear_pre1's output = the seed of irbfn_net_vjp on the stage descriptor) and the
+ * gradients of linear_pre2 (gw2 [H1,H2], gb2 [H2]) and linear (gw3 [H2,O], gb3 [O]).  O <= 16.  Deterministic. */
+int64_t irbfn_mlp_head_vjp_workspace_bytes(int H1, int H2, int O);
+int irbfn_mlp_head_vjp(const float* h1_dev, const float* w2_dev, const float* b2_dev, const float* w3_dev,
+                       const float* gout_dev, float* gh1_dev, float* gw2_dev, float* gb2_dev, float* gw3_dev,
+                       float* gb3_dev, int64_t B, int H1, int H2, int O, void* ws_dev, int64_t ws_bytes, void* stream);
 
 /* Diagnostics */
 int irbfn_abi_version(void);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "irbfn_train_loss_partials": (_i, []),
     "irbfn_train_seeds_oneint": (_i, [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_train_seeds_fullint": (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
+    "irbfn_train_seeds_frenet_fullint": (_i, [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_adam_clip_step": (_i, [_fp, _fp, _fp, _fp, _i64, _vp, _f, _f, _f, _f, _f, _fp, _vp]),
     "irbfn_plan_queries_cartesian": (_i, [_fp, _fp, _fp, _fp, _ip, _i64, _vp]),
     "irbfn_plan_queries_frenet": (_i, [_fp, _fp, _fp, _fp, _ip, _i64, _vp]),
@@ -54,6 +55,8 @@ SIGNATURES = {
     "irbfn_cluster_gate": (_i, [_fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_net_forward_gamma": (_i, [_vp, _fp, _fp, _fp, _i64, _vp]),
     "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),
+    "irbfn_mlp_head_vjp_workspace_bytes": (_i64, [_i, _i, _i]),
+    "irbfn_mlp_head_vjp": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "irbfn_abi_version": (_i, []),
     "irbfn_device_count": (_i, []),
     "irbfn_last_hip_error": (_i, []),

@@ -5,12 +5,14 @@
 //
 //   seeds_oneint  : loss_fn of train_step_oneint  (scripts/train_nmpc.py:268-295)
 //   seeds_fullint : loss_fn of train_step_fullint (scripts/train_nmpc.py:306-390)
+//   seeds_frenet_fullint : loss_fn of the Frenet train_step_fullint (scripts/train_nmpc_frenet.py:394-421)
 //   adam_clip     : optax.chain(clip_by_global_norm(max_norm), adam(lr)) + apply_gradients
 //                   (scripts/train_nmpc.py:231-233, :299)
 // All reductions are two-stage with a fixed order (deterministic).
 #include <string.h>
 
 #include "common.h"
+#include "rollout_adjoint.h"
 #include "rollout_step.h"
 
 namespace irbfn {
@@ -140,6 +142,62 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
   if (threadIdx.x == 0) loss_part[blockIdx.x] = tot;
 }
 
+// ---- Frenet train_step_fullint (scripts/train_nmpc_frenet.py:394-421) -------------------------------------------
+// x[B,8] = [ey, delta, vx_car, vy_car, vx_goal, wz, epsi, curv]; initial_state = x[:, [0,0,1,2,3,5,6,7]] (:398);
+// loss = mean|y_pred - y| + mean|integrate_frenet_mult([init, y_pred]) - integrate_frenet_mult([init, y])|
+// (:402-412; all T states, all 8 components).  gy = d loss / d y_pred through the T-step Frenet roll-out
+// (rollout_adjoint.h: the adjoint of dynamics.py:190-290, low-speed RHS).  O = 2T.
+template <int TMAX>
+__global__ __launch_bounds__(256) void seeds_frenet_fullint_kernel(const float* __restrict__ x, const float* __restrict__ yp,
+                                                                   const float* __restrict__ y, float* __restrict__ gy,
+                                                                   float* __restrict__ loss_part, long B, int D, int T,
+                                                                   DynParams dp, float tie) {
+  __shared__ float sm[256];
+  const int O = 2 * T;
+  const float inv_y = 1.0f / ((float)B * (float)O), inv_s = 1.0f / ((float)B * (float)T * 8.0f);
+  float lsum = 0.0f;
+  for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
+    const float* xb = x + b * D;
+    float sa[8] = {xb[0], xb[0], xb[1], xb[2], xb[3], xb[5], xb[6], xb[7]};
+    float sp[8] = {xb[0], xb[0], xb[1], xb[2], xb[3], xb[5], xb[6], xb[7]};
+    const float cur = sp[7];
+    float park[TMAX][4], seed[TMAX][8];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < T) {
+        frenet_step(sa, y[b * O + t], y[b * O + T + t], dp);        // actual_states (:407)
+        vjp_park<IRBFN_ROLLOUT_FRENET_LS>(sp, park[t]);
+        frenet_step(sp, yp[b * O + t], yp[b * O + T + t], dp);      // pred_states   (:408)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = sp[i] - sa[i];
+          lsum += fabsf(d) * inv_s;
+          seed[t][i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_s;      // d|.| = sign
+        }
+      }
+    }
+    float lam[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = TMAX - 1; t >= 0; --t) {
+      if (t < T) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lam[i] += seed[t][i];
+        float ga, gsv;
+        vjp_back_step<IRBFN_ROLLOUT_FRENET_LS>(park[t], yp[b * O + t], yp[b * O + T + t], lam, cur, tie, dp, ga, gsv);
+        gy[b * O + t] = ga;
+        gy[b * O + T + t] = gsv;
+      }
+    }
+    for (int o = 0; o < O; ++o) {                             // pred_loss = |y_pred - y|.mean()  (:401)
+      const float d = yp[b * O + o] - y[b * O + o];
+      lsum += fabsf(d) * inv_y;
+      gy[b * O + o] += (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_y;
+    }
+  }
+  const float tot = block_sum_256(lsum, sm);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
   __shared__ float sm[256];
   float v = 0.0f;
@@ -221,6 +279,27 @@ int irbfn_train_seeds_fullint(const float* x_dev, const float* y_pred_dev, const
   else
     hipLaunchKernelGGL((seeds_fullint_kernel<64>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, clip_tie);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, kRedBlocks, loss_dev);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+int irbfn_train_seeds_frenet_fullint(const float* x_dev, const float* y_pred_dev, const float* y_dev,
+                                     const float* dyn_params_host, float clip_tie, float* gy_dev, float* loss_dev,
+                                     float* partials_dev, int64_t B, int D, int T, void* stream) {
+  if (B < 0 || D < 8 || T < 1 || T > 16 || !dyn_params_host) return IRBFN_ERR_BAD_ARG;
+  if (B > 0 && (!x_dev || !y_pred_dev || !y_dev || !gy_dev)) return IRBFN_ERR_BAD_ARG;
+  if (!loss_dev || !partials_dev) return IRBFN_ERR_BAD_ARG;
+  DynParams dp;
+  memcpy(dp.p, dyn_params_host, sizeof(dp.p));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (T <= 5)
+    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<5>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+                       partials_dev, (long)B, D, T, dp, clip_tie);
+  else
+    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<16>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+                       partials_dev, (long)B, D, T, dp, clip_tie);
   IRBFN_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, kRedBlocks, loss_dev);
   IRBFN_HIP_CHECK(hipGetLastError());

@@ -299,8 +299,9 @@ class DeeperWCRBFNet:
     """``DeeperWCRBFNet`` of the reference (src/irbfn_mpc/model.py:201-289): the RBF stage followed by
     Dense(64) -> relu -> Dense(64) -> relu -> Dense(out_features).  Parameter pytree (checkpoint layout):
     ``{"rbf_list": {centers, log_sigs}, "linear_pre1": {kernel[K,64], bias}, "linear_pre2":
-    {kernel[64,64], bias}, "linear": {kernel[64,O], bias}}``.  Forward only: the RBF stage + linear_pre1
-    run in the fused RBF kernel (64-wide Dense), the rest in ``irbfn_mlp_head_forward``."""
+    {kernel[64,64], bias}, "linear": {kernel[64,O], bias}}``.  The RBF stage + linear_pre1 run in the fused RBF
+    kernel (64-wide Dense), the rest in ``irbfn_mlp_head_forward``; ``vjp`` = ``irbfn_mlp_head_vjp`` followed by the
+    RBF-stage VJP seeded with the cotangent of linear_pre1's output."""
 
     HIDDEN = 64          # model.py:254-255
 
@@ -344,6 +345,42 @@ class DeeperWCRBFNet:
                                         B, H, H, O, _stream_ptr(torch))
         _lib.check(st, "irbfn_mlp_head_forward")
         return like_input(out, x, torch)
+
+
+    def _vjp_impl(self, params: dict, x, gout):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        H, O = self.HIDDEN, self.out_features
+        stage_params = {"rbf_list": p["rbf_list"], "linear": p["linear_pre1"]}
+        xd, gd = to_device_f32(x, torch), to_device_f32(gout, torch)
+        B = xd.shape[0]
+        if tuple(gd.shape) != (B, O):
+            raise ValueError(f"gout must have shape ({B}, {O})")
+        h1 = self.stage.apply(stage_params, xd)
+        w2, b2, w3 = (to_device_f32(a, torch) for a in (p["linear_pre2"]["kernel"], p["linear_pre2"]["bias"], p["linear"]["kernel"]))
+        dev = xd.device
+        gh1 = torch.empty((B, H), dtype=torch.float32, device=dev)
+        gw2, gb2 = torch.empty((H, H), dtype=torch.float32, device=dev), torch.empty((H,), dtype=torch.float32, device=dev)
+        gw3, gb3 = torch.empty((H, O), dtype=torch.float32, device=dev), torch.empty((O,), dtype=torch.float32, device=dev)
+        nbytes = int(lib.irbfn_mlp_head_vjp_workspace_bytes(H, H, O))
+        if nbytes < 0:
+            _lib.check(nbytes, "irbfn_mlp_head_vjp_workspace_bytes")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        st = lib.irbfn_mlp_head_vjp(_ptr(h1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(gd), _ptr(gh1), _ptr(gw2), _ptr(gb2),
+                                    _ptr(gw3), _ptr(gb3), B, H, H, O, _ptr(ws), nbytes, _stream_ptr(torch))
+        _lib.check(st, "irbfn_mlp_head_vjp")
+        gs = self.stage.vjp(stage_params, xd, gh1)["params"]
+        conv = lambda t: like_input(t, x, torch)
+        return {"params": {"rbf_list": {k: conv(v) for k, v in gs["rbf_list"].items()},
+                           "linear_pre1": {k: conv(v) for k, v in gs["linear"].items()},
+                           "linear_pre2": {"kernel": conv(gw2), "bias": conv(gb2)},
+                           "linear": {"kernel": conv(gw3), "bias": conv(gb3)}}}
+
+    def vjp(self, params: dict, x, gout) -> dict:
+        """Parameter VJP of the whole model: cotangent gout[B,O] -> gradient pytree with the structure of ``params``
+        (what ``jax.value_and_grad`` returns for a DeeperWCRBFNet, scripts/train_nmpc_frenet.py:388-389,416-417)."""
+        return self._vjp_impl(params, x, gout)
 
 
 class ClusterWCRBFNet:

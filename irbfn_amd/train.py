@@ -118,6 +118,25 @@ def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[
     return state, _backward_and_update(state, xd, gy, torch, lib)
 
 
+def train_step_frenet_fullint(state: TrainState, x, y, dyn_params, clip_tie: float = 0.5) -> Tuple[TrainState, "object"]:
+    """Frenet ``train_step_fullint`` (scripts/train_nmpc_frenet.py:394-421).  x [B,8], y [B,2T] (T <= 16; the
+    reference's tables hold T = 5) -> (state, loss[1] on device).  The gradient runs through
+    ``integrate_frenet_mult`` on device (the adjoint of the low-speed Frenet model)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    xd, yd = to_device_f32(x, torch), to_device_f32(y, torch)
+    B, O = yd.shape
+    if xd.shape[1] != 8 or O != state.net.out_features or O % 2 or O // 2 > 16:
+        raise ValueError("train_step_frenet_fullint needs x [B,8] and y [B, out_features = 2T], T <= 16")
+    y_pred = state.net.apply(state.params, xd)
+    gy = torch.empty_like(y_pred)
+    keep, pp = _dyn(dyn_params)
+    st = lib.irbfn_train_seeds_frenet_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy),
+                                              _ptr(state.loss), _ptr(state.partials), B, 8, O // 2, _stream_ptr(torch))
+    _lib.check(st, "irbfn_train_seeds_frenet_fullint")
+    return state, _backward_and_update(state, xd, gy, torch, lib)
+
+
 def train_epoch(state: TrainState, table, batch_size: int, only_onestep: bool = False, dyn_params=None):
     """scripts/train_nmpc.py:455-486: one pass over a ``tables.DeviceTable``.  Returns (state, losses [steps]
     on the device) -- the reference fetches every batch loss to the host (``jax.device_get``, :477-481);

@@ -638,6 +638,24 @@ def train_fullint_loss(cfg, params, x, y):
     return absf(y_pred[:, cols] - y[:, cols]).mean() + absf(fin_p - fin_a).mean()   # :386-390
 
 
+def train_frenet_fullint_loss(cfg, params, x, y, dyn_params):
+    """scripts/train_nmpc_frenet.py:394-421 -- loss of the Frenet train_step_fullint: L1 on the predictions + L1 on
+    ALL states of the T-step Frenet roll-out (works on torch tensors for autograd or on numpy)."""
+    xp = _ns(x)
+    init = x[:, [0, 0, 1, 2, 3, 5, 6, 7]]                                      # :398
+    y_pred = wcrbfnet_apply(cfg, params, x)                                    # :401
+    if xp is _NP:
+        x_pred_u, x_u = np.hstack((init, y_pred)), np.hstack((init, y))
+        absf = np.abs
+    else:
+        import torch
+        x_pred_u, x_u = torch.hstack((init, y_pred)), torch.hstack((init, y))
+        absf = lambda t: t.abs()
+    actual = integrate_frenet_mult(x_u, dyn_params)                            # :407
+    pred = integrate_frenet_mult(x_pred_u, dyn_params)                         # :408
+    return absf(y_pred - y).mean() + absf(pred - actual).mean()                # :402,409,412
+
+
 def clip_by_global_norm(grads_flat: np.ndarray, max_norm: float) -> np.ndarray:
     """optax.clip_by_global_norm (third-party, version un-pinned by pyproject.toml:7 -- parity unpinned):
     g if ||g|| < max_norm else g / ||g|| * max_norm."""

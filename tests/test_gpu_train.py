@@ -89,6 +89,40 @@ def test_train_step_fullint(gpu):
     assert np.abs(state.flat.cpu().numpy() - p_ref).max() <= 5e-5 + 1e-6 * np.abs(p_ref).max()
 
 
+def test_train_step_frenet_fullint(gpu):
+    """Frenet train_step_fullint (scripts/train_nmpc_frenet.py:394-421) on the reference's trained 12-region Frenet
+    checkpoint: loss, parameter gradient (through integrate_frenet_mult) and the Adam update against
+    torch.autograd of the restatement."""
+    cfg, params, x0, *_ = load_ckpt_fixture("dnmpc_12regions_frenet_l1_bigdata")
+    rng = np.random.default_rng(9)
+    T = 5
+    cfg = dict(cfg, out_features=2 * T)                      # the fixture net has O = 2: widen the Dense to 2T = 10
+    K = cfg["num_kernels"]
+    params = orc.cast_params(params, np.float32)
+    params["params"]["linear"] = {"kernel": (rng.normal(size=(K, 2 * T)) * 0.05).astype(np.float32),
+                                  "bias": (rng.normal(size=(2 * T,)) * 0.1).astype(np.float32)}
+    B = 300
+    ns = len(cfg["activation_idx"])
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    x = rng.uniform(lo, hi, size=(B, 8)).astype(np.float32)
+    x[:, 7] = rng.normal(size=B).astype(np.float32) * 0.05   # curvature of a race track: 1 - ey * cur stays away from 0
+    x[:, 0] = rng.normal(size=B).astype(np.float32) * 0.2
+    y = np.hstack([rng.normal(size=(B, T)) * 2, rng.normal(size=(B, T)) * 0.5]).astype(np.float32)
+    net = WCRBFNet.from_config(cfg)
+    state = train.TrainState.create(net, params, lr=1e-3, max_grad_norm=1.0)
+    n = state.flat.numel()
+    loss_ref, g_ref, p_ref, _, _ = _oracle_step(
+        cfg, orc.cast_params(params, np.float64), x, y,
+        lambda tp: orc.train_frenet_fullint_loss(cfg, tp, torch.tensor(x, dtype=torch.float64),
+                                                 torch.tensor(y, dtype=torch.float64), DP),
+        1e-3, 1.0, np.zeros(n), np.zeros(n), 1)
+    state, loss = train.train_step_frenet_fullint(state, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), DP)
+    assert abs(float(loss) - loss_ref) <= 3e-5 * abs(loss_ref), (float(loss), loss_ref)
+    g_gpu = state.g.cpu().numpy()
+    assert np.abs(g_gpu - g_ref).max() <= 5e-4 * np.abs(g_ref).max(), np.abs(g_gpu - g_ref).max() / np.abs(g_ref).max()
+    assert np.abs(state.flat.cpu().numpy() - p_ref).max() <= 5e-5 + 1e-6 * np.abs(p_ref).max()
+
+
 def test_training_reduces_the_loss(gpu):
     cfg = dict(configs.model_card(2), num_kernels=256, out_features=2)
     net = WCRBFNet.from_config(cfg)
@@ -136,3 +170,34 @@ def test_train_epoch_over_device_table(gpu, tmp_path):
         assert losses.shape == (5,)
         means.append(float(losses.mean()))
     assert np.isfinite(means).all() and means[-1] < 0.95 * means[0], means
+
+
+def test_deeper_wcrbfnet_vjp_on_the_reference_checkpoint(gpu):
+    """DeeperWCRBFNet (model.py:201-289) on the reference's trained `..._5stepint_deeper` checkpoint: all eight
+    gradient leaves of a random cotangent against torch.autograd of the restatement; deterministic."""
+    from conftest import load_deeper_fixture
+    from irbfn_amd.model import DeeperWCRBFNet
+    cfg, params, x, out64 = load_deeper_fixture()
+    rng = np.random.default_rng(3)
+    ns = len(cfg["activation_idx"])
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    B = 700
+    xx = rng.uniform(lo, hi, size=(B, cfg["in_features"])).astype(np.float32)
+    xx[:64] = x.astype(np.float32)
+    O = cfg["out_features"]
+    g = rng.normal(size=(B, O)).astype(np.float32)
+    p32 = {"params": {k: {n: np.asarray(v, np.float32) for n, v in d.items()} for k, d in params["params"].items()}}
+    net = DeeperWCRBFNet.from_config(cfg)
+    a = net.vjp(p32, torch.from_numpy(xx).cuda(), torch.from_numpy(g).cuda())["params"]
+    a2 = net.vjp(p32, torch.from_numpy(xx).cuda(), torch.from_numpy(g).cuda())["params"]
+    tp = {"params": {k: {n: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for n, v in d.items()}
+                     for k, d in p32["params"].items()}}
+    out = orc.deeper_wcrbfnet_apply(cfg, tp, torch.tensor(xx, dtype=torch.float64))
+    (out * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    for grp in ("rbf_list", "linear_pre1", "linear_pre2", "linear"):
+        for name, t in tp["params"][grp].items():
+            ref = t.grad.numpy()
+            got = a[grp][name].cpu().numpy()
+            assert torch.equal(a[grp][name], a2[grp][name])
+            e = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300)
+            assert e <= 2e-4, (grp, name, e)
