@@ -247,6 +247,19 @@ int irbfn_lut_nearest(const float* inputs_dev, const float* table_dev, const flo
                       float* dist_dev, float* out_dev, int64_t N, int64_t B, int D, int OW, void* ws_dev,
                       int64_t ws_bytes, void* stream);
 
+/* Way-point geometry of the planners' pure-pursuit front end, batched over B query points against ONE piecewise-linear
+ * trajectory [N,2] (N <= 4096, float64 device arrays as the NumPy callers hold them):
+ * irbfn_nearest_point = nearest_point (src/irbfn_mpc/planner_utils.py:109-146): projection [B,2], distance, t in [0,1]
+ *   and segment index of the closest point (first minimum, as np.argmin);
+ * irbfn_intersect_point = intersect_point (:149-233): first point one `radius` away along the trajectory from
+ *   t_start (= i + t, may be NULL = 0), with wrap-around; found[b] = 0 where the reference returns (None, None, None)
+ *   (then first_p / first_t are NaN); first_i may be -1 (the closing segment, :206). */
+int irbfn_nearest_point(const double* points_dev, const double* trajectory_dev, double* proj_dev, double* dist_dev,
+                        double* t_dev, int32_t* seg_dev, int64_t B, int N, void* stream);
+int irbfn_intersect_point(const double* points_dev, const double* trajectory_dev, const double* t_start_dev, float radius,
+                          int wrap, float* first_p_dev, int32_t* first_i_dev, float* first_t_dev, int32_t* found_dev,
+                          int64_t B, int N, void* stream);
+
 /* ClusterWCRBFNet (src/irbfn_mpc/model.py:341-414): the region weights are a learned softmax gate instead of the
  * tanh indicator.  irbfn_cluster_gate: logits = x Wc + bc [B,R] (second output of the reference module) and
  * gamma = softmax(logits) [B,R]; wc [D,R], bc [R] device pointers.  irbfn_net_forward_gamma: the fused

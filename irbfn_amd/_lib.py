@@ -52,6 +52,8 @@ SIGNATURES = {
     "irbfn_lut_grid_lookup": (_i, [_fp, _ip, _ip, _fp, _fp, _ip, _fp, _i64, _i, _i, _vp]),
     "irbfn_lut_nearest_workspace_bytes": (_i64, [_i64, _i64]),
     "irbfn_lut_nearest": (_i, [_fp, _fp, _fp, _ip, _fp, _fp, _i64, _i64, _i, _i, _vp, _i64, _vp]),
+    "irbfn_nearest_point": (_i, [_fp, _fp, _fp, _fp, _fp, _ip, _i64, _i, _vp]),
+    "irbfn_intersect_point": (_i, [_fp, _fp, _fp, _f, _i, _fp, _ip, _fp, _ip, _i64, _i, _vp]),
     "irbfn_cluster_gate": (_i, [_fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp]),
     "irbfn_net_forward_gamma": (_i, [_vp, _fp, _fp, _fp, _i64, _vp]),
     "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),

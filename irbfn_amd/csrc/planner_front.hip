@@ -223,6 +223,104 @@ static int nearest_launch(const float* inputs, const float* x, float* pd, long* 
 
 using namespace irbfn;
 
+// ---- way-point geometry of the pure-pursuit front end (src/irbfn_mpc/planner_utils.py:109-240) -----------------
+// The reference runs nearest_point / intersect_point once per planner tick under numba; here they are batched over B
+// query points against ONE piecewise-linear trajectory (staged in LDS), one lane per point.  The arithmetic types
+// follow the reference line by line: float32 segment vectors / squared lengths / dot products, float64 everything
+// else in nearest_point (:125-141); float32 trajectory, +1e-6f end points, float32 t in intersect_point (:160-170),
+// with the point kept in float64 as the callers pass it.  numba's typing of the mixed expressions cannot be
+// checked here (numba is not importable): parity unpinned, tested against the NumPy statement of the same lines.
+struct WayArgs {
+  const double* __restrict__ pts;    // [B][2]
+  const double* __restrict__ traj;   // [N][2]
+  long B;
+  int N;
+};
+
+__global__ __launch_bounds__(256) void nearest_point_kernel(const WayArgs a, double* __restrict__ proj,
+                                                            double* __restrict__ dist, double* __restrict__ tt,
+                                                            int* __restrict__ seg) {
+  extern __shared__ double wp[];                 // [N][2]
+  for (int i = threadIdx.x; i < 2 * a.N; i += blockDim.x) wp[i] = a.traj[i];
+  __syncthreads();
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double px = a.pts[2 * b], py = a.pts[2 * b + 1];
+  double best = INFINITY, bt = 0.0, bx = 0.0, by = 0.0;
+  int bi = 0;
+  for (int i = 0; i + 1 < a.N; ++i) {
+    const double x0 = wp[2 * i], y0 = wp[2 * i + 1];
+    const float dx = (float)(wp[2 * i + 2] - x0), dy = (float)(wp[2 * i + 3] - y0);       // diffs.astype(float32) :125
+    const float l2 = dx * dx + dy * dy;                                                  // :126
+    const float lx = (float)(px - x0), ly = (float)(py - y0);                            // :129
+    const float dot = lx * dx + ly * dy;                                                 // np.dot of two float32 pairs :130
+    double t = (double)dot / (double)l2;                                                 // :131
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);                                             // :132-133 (nan stays)
+    const double qx = x0 + t * (double)dx, qy = y0 + t * (double)dy;                     // :134
+    const double ex = px - qx, ey = py - qy;
+    const double d = sqrt(ex * ex + ey * ey);                                            // :137-138
+    if (d < best) { best = d; bt = t; bx = qx; by = qy; bi = i; }                        // np.argmin: first minimum
+  }
+  proj[2 * b] = bx; proj[2 * b + 1] = by;
+  dist[b] = best; tt[b] = bt; seg[b] = bi;
+}
+
+__device__ __forceinline__ bool circle_hit(const double* wp, int N, int i, double px, double py, float radius,
+                                           bool first, float start_t, float& t_out, float& qx, float& qy) {
+  const int i0 = ((i % N) + N) % N, i1 = (((i + 1) % N) + N) % N;
+  const float sx = (float)wp[2 * i0], sy = (float)wp[2 * i0 + 1];                         // trajectory.astype(float32) :160
+  const float ex = (float)wp[2 * i1] + 1e-6f, ey = (float)wp[2 * i1 + 1] + 1e-6f;         // :163
+  const float vx = ex - sx, vy = ey - sy;
+  const float av = vx * vx + vy * vy;                                                    // :166
+  const double bq = 2.0 * ((double)vx * ((double)sx - px) + (double)vy * ((double)sy - py));   // :167
+  const double cq = (double)(sx * sx + sy * sy) + (px * px + py * py) - 2.0 * ((double)sx * px + (double)sy * py) -
+                    (double)radius * (double)radius;                                     // :168-173
+  double disc = bq * bq - 4.0 * (double)av * cq;                                         // :174
+  if (disc < 0.0 || disc != disc) return false;
+  disc = sqrt(disc);
+  const double t1 = (-bq - disc) / (2.0 * (double)av), t2 = (-bq + disc) / (2.0 * (double)av);   // :182-183
+  double t;
+  if (first) {                                                                           // :184-193
+    if (t1 >= 0.0 && t1 <= 1.0 && t1 >= (double)start_t) t = t1;
+    else if (t2 >= 0.0 && t2 <= 1.0 && t2 >= (double)start_t) t = t2;
+    else return false;
+  } else {                                                                               // :194-203
+    if (t1 >= 0.0 && t1 <= 1.0) t = t1;
+    else if (t2 >= 0.0 && t2 <= 1.0) t = t2;
+    else return false;
+  }
+  t_out = (float)t;
+  qx = (float)((double)sx + t * (double)vx);
+  qy = (float)((double)sy + t * (double)vy);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void intersect_point_kernel(const WayArgs a, const double* __restrict__ t0, float radius,
+                                                              int wrap, float* __restrict__ first_p, int* __restrict__ first_i,
+                                                              float* __restrict__ first_t, int* __restrict__ found) {
+  extern __shared__ double wp[];
+  for (int i = threadIdx.x; i < 2 * a.N; i += blockDim.x) wp[i] = a.traj[i];
+  __syncthreads();
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double px = a.pts[2 * b], py = a.pts[2 * b + 1];
+  const double ts = t0 ? t0[b] : 0.0;
+  const int start_i = (int)ts;                                                           // :155
+  const float start_t = (float)fmod(ts, 1.0);                                            // :156
+  float t = NAN, qx = NAN, qy = NAN;                                                     // (None, None, None)
+  int fi = 0, hit = 0;
+  for (int i = start_i; i + 1 < a.N && !hit; ++i)
+    if (circle_hit(wp, a.N, i, px, py, radius, i == start_i, start_t, t, qx, qy)) { fi = i; hit = 1; }
+  if (wrap && !hit)                                                                      // :205-231: i runs from -1
+    for (int i = -1; i < start_i && !hit; ++i)
+      if (circle_hit(wp, a.N, i, px, py, radius, false, 0.0f, t, qx, qy)) { fi = i; hit = 1; }
+  found[b] = hit;
+  first_i[b] = fi;
+  first_t[b] = t;
+  first_p[2 * b] = qx;
+  first_p[2 * b + 1] = qy;
+}
+
 extern "C" {
 
 int irbfn_plan_queries_cartesian(const double* pose_dev, const double* goal_dev, float* x_dev, float* state0_dev,
@@ -299,6 +397,37 @@ int irbfn_lut_nearest(const float* inputs_dev, const float* table_dev, const flo
   IRBFN_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(lut_nearest_final_kernel, dim3((unsigned)B), dim3(64), 0, s, pd, pi, nblocks, table_dev,
                      reinterpret_cast<long*>(idx_dev), dist_dev, out_dev, OW);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+
+/* planner_utils.py:109-146 and :149-233, batched over B query points against one trajectory (see the kernels). */
+int irbfn_nearest_point(const double* points_dev, const double* trajectory_dev, double* proj_dev, double* dist_dev,
+                        double* t_dev, int32_t* seg_dev, int64_t B, int N, void* stream) {
+  if (B < 0 || N < 2) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!points_dev || !trajectory_dev || !proj_dev || !dist_dev || !t_dev || !seg_dev) return IRBFN_ERR_BAD_ARG;
+  const size_t lds = (size_t)N * 2 * sizeof(double);
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;          // <= 4096 way-points
+  WayArgs a{points_dev, trajectory_dev, (long)B, N};
+  hipLaunchKernelGGL(nearest_point_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     a, proj_dev, dist_dev, t_dev, seg_dev);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+int irbfn_intersect_point(const double* points_dev, const double* trajectory_dev, const double* t_start_dev, float radius,
+                          int wrap, float* first_p_dev, int32_t* first_i_dev, float* first_t_dev, int32_t* found_dev,
+                          int64_t B, int N, void* stream) {
+  if (B < 0 || N < 2) return IRBFN_ERR_BAD_ARG;
+  if (B == 0) return IRBFN_OK;
+  if (!points_dev || !trajectory_dev || !first_p_dev || !first_i_dev || !first_t_dev || !found_dev) return IRBFN_ERR_BAD_ARG;
+  const size_t lds = (size_t)N * 2 * sizeof(double);
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  WayArgs a{points_dev, trajectory_dev, (long)B, N};
+  hipLaunchKernelGGL(intersect_point_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     a, t_start_dev, radius, wrap, first_p_dev, first_i_dev, first_t_dev, found_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }

@@ -752,3 +752,75 @@ def lut_nearest(inputs, lookup):
     """explicit_planner.py:219, :383 -- scipy.spatial.KDTree(inputs).query(lookup) -> (distance, index)."""
     import scipy.spatial as ss
     return ss.KDTree(inputs).query(lookup)
+
+
+# --------------------------------------------------------------------------
+# f-4 way-point geometry -- src/irbfn_mpc/planner_utils.py:109-233 (numba in the reference: the same lines without
+# the decorator; numba's typing of the mixed float32 / float64 expressions cannot be checked here: parity unpinned)
+# --------------------------------------------------------------------------
+def nearest_point(point, trajectory):
+    diffs = (trajectory[1:, :] - trajectory[:-1, :]).astype(np.float32)           # :125
+    l2s = diffs[:, 0] ** 2 + diffs[:, 1] ** 2                                     # :126
+    dots = np.empty((trajectory.shape[0] - 1,))
+    for i in range(dots.shape[0]):
+        lhs = (point - trajectory[i, :]).astype(np.float32)                       # :129
+        dots[i] = np.float32(lhs[0] * diffs[i, 0]) + np.float32(lhs[1] * diffs[i, 1])   # np.dot of float32 pairs :130
+    t = dots / l2s
+    t[t < 0.0] = 0.0
+    t[t > 1.0] = 1.0
+    projections = trajectory[:-1, :] + (t * diffs.T).T                            # :134
+    dists = np.empty((projections.shape[0],))
+    for i in range(dists.shape[0]):
+        temp = point - projections[i]
+        dists[i] = np.sqrt(np.sum(temp * temp))
+    k = int(np.argmin(dists))
+    return projections[k], dists[k], t[k], k
+
+
+def intersect_point(point, radius, trajectory, t=0.0, wrap=False):
+    start_i = int(t)
+    start_t = np.float32(t % 1.0)
+    traj = np.ascontiguousarray(trajectory).astype(np.float32)                    # :160
+    n = traj.shape[0]
+    radius = np.float32(radius)
+
+    def hit(i, first):
+        start = traj[i % n, :]
+        end = traj[(i + 1) % n, :] + np.float32(1e-6)                             # :163
+        V = end - start
+        a = np.float32(V[0] * V[0]) + np.float32(V[1] * V[1])
+        d = start.astype(np.float64) - point
+        b = 2.0 * (float(V[0]) * d[0] + float(V[1]) * d[1])
+        c = (float(np.float32(start[0] * start[0]) + np.float32(start[1] * start[1])) + (point[0] * point[0] + point[1] * point[1])
+             - 2.0 * (float(start[0]) * point[0] + float(start[1]) * point[1]) - float(radius) * float(radius))
+        disc = b * b - 4.0 * float(a) * c
+        if not disc >= 0:
+            return None
+        disc = np.sqrt(disc)
+        t1, t2 = (-b - disc) / (2.0 * float(a)), (-b + disc) / (2.0 * float(a))
+        if first:
+            if 0.0 <= t1 <= 1.0 and t1 >= start_t:
+                tt = t1
+            elif 0.0 <= t2 <= 1.0 and t2 >= start_t:
+                tt = t2
+            else:
+                return None
+        else:
+            if 0.0 <= t1 <= 1.0:
+                tt = t1
+            elif 0.0 <= t2 <= 1.0:
+                tt = t2
+            else:
+                return None
+        return (start.astype(np.float64) + tt * V.astype(np.float64)).astype(np.float32), i, np.float32(tt)
+
+    for i in range(start_i, n - 1):
+        r = hit(i, i == start_i)
+        if r is not None:
+            return r
+    if wrap:
+        for i in range(-1, start_i):
+            r = hit(i, False)
+            if r is not None:
+                return r
+    return None, None, None

@@ -145,3 +145,29 @@ def test_lut_nearest_matches_kdtree(gpu, D, N, B):
     t2 = explicit_planner.ExplicitTable(dup, np.zeros((200, 5, 2)))
     i2, *_ = t2.nearest(inputs[:100])
     np.testing.assert_array_equal(i2.cpu().numpy(), np.arange(100))
+
+
+def test_waypoint_geometry_matches_the_restatement(gpu):
+    """nearest_point / intersect_point (planner_utils.py:109-233), batched, against the NumPy statement of the same
+    lines point by point (numba semantics themselves: parity unpinned)."""
+    from irbfn_amd import planner_utils as pu
+    rng = np.random.default_rng(8)
+    th = np.linspace(0, 2 * np.pi, 200, endpoint=False)
+    traj = np.stack([20 * np.cos(th) + 3 * np.cos(3 * th), 12 * np.sin(th)], axis=1)        # a closed race line
+    pts = traj[rng.integers(0, 200, size=500)] + rng.normal(size=(500, 2)) * 0.8
+    proj, dist, t, seg = (v.cpu().numpy() for v in pu.nearest_point(pts, traj))
+    for b in range(500):
+        rp, rd, rt, ri = orc.nearest_point(pts[b], traj)
+        assert seg[b] == ri and abs(dist[b] - rd) <= 1e-6 and abs(t[b] - rt) <= 1e-5 and np.abs(proj[b] - rp).max() <= 1e-5
+    start = seg + t
+    for wrap, radius in ((False, 1.5), (True, 1.5), (True, 60.0)):
+        fp, fi, ft, found = (v.cpu().numpy() for v in pu.intersect_point(pts, radius, traj, start, wrap=wrap))
+        nfound = 0
+        for b in range(500):
+            rp, ri, rt = orc.intersect_point(pts[b], radius, traj, float(start[b]), wrap)
+            if rp is None:
+                assert found[b] == 0 and np.isnan(fp[b]).all()
+            else:
+                nfound += 1
+                assert found[b] == 1 and fi[b] == ri and abs(ft[b] - rt) <= 2e-4 and np.abs(fp[b] - rp).max() <= 1e-3
+        assert (nfound > 400) if radius < 10 else (nfound == 0)      # a 60 m look-ahead circle misses a 23 m track
