@@ -415,8 +415,9 @@ def single_gpu_extras(net, params, x, configs, torch):
                      "what": "issued f16 MFMA flops: 3 products x 7 column tiles of 16 (O = 100 padded to 112)"},
         "algorithmic_fp32_tflops": pairs4 * (3 * 7 + 2 + 200) / t / 1e12}
     del x4
-    # BASELINE config 5: 16384-centre inverse-multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs the reduction
-    # "cast as MFMA GEMM": K1h at float32 accuracy (hi/lo f16 operand pairs) and with plain f16 operands
+    # BASELINE config 5 ("fp32 vs bf16, reduction cast as MFMA GEMM, utilisation reported"): 16384-centre inverse-
+    # multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs K1h at float32 accuracy (hi/lo f16 operand pairs), with
+    # plain f16 operands and with plain bf16 operands
     card5 = configs.model_card(5)
     net5 = WCRBFNet.from_config(card5)
     p5 = distributed.params_to_device(configs.synth_params(5))
@@ -428,7 +429,8 @@ def single_gpu_extras(net, params, x, configs, torch):
     ref_out = None
     for key, opts in (("fp32_valu_K1", {"fwd_kernel": _lib.FWD_K1}),
                       ("f16x3_mfma_K1h_fp32_accurate", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 3}),
-                      ("f16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 1})):
+                      ("f16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 1}),
+                      ("bf16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 2})):
         net5.set_options(**opts)
         t = _time(lambda: net5(x5), 3, torch)
         o5 = net5(x5)[:4096].float().cpu().numpy()

@@ -104,8 +104,9 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
 typedef enum irbfn_option {
   IRBFN_OPT_FWD_KERNEL = 0,    /* irbfn_fwd_kernel below; default IRBFN_FWD_AUTO */
   IRBFN_OPT_FWD_SMALL = 1,     /* 1 (default): B <= 64 runs on the latency kernel K1s; 0: never */
-  IRBFN_OPT_FWD_F16_TERMS = 2, /* 3 (default): hi/lo operand pairs, float32-grade result;
-                                  1: plain f16 operands (~1e-4 relative) -- reporting only */
+  IRBFN_OPT_FWD_F16_TERMS = 2, /* MFMA operands of K1h.  3 (default): (hi, lo) f16 pairs, float32-grade result;
+                                  1: plain f16 operands (~1e-4 relative), 2: plain bf16 operands (~4e-3; O <= 16 only)
+                                  -- the two reduced-precision variants BASELINE config 5 asks to report */
   IRBFN_OPT_FWD_F16_MINB = 3,  /* smallest batch K1h takes in automatic mode (default 65) */
   IRBFN_OPT_FWD_Q = 4,         /* K1: queries per lane (1, 2) */
   IRBFN_OPT_FWD_NW = 5,        /* K1 / K1m: waves per workgroup */

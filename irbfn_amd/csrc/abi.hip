@@ -135,7 +135,7 @@ int irbfn_net_set_option(irbfn_net* net, int option, int value) {
     case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1H) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2H) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_SMALL: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
-    case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 3) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 2 && value != 3) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_Q: if (value > 2) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_NW: if (value > 16) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_QJ: if (value != 0 && value != 1 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;

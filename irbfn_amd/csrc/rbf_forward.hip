@@ -297,7 +297,8 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   if (S > 8 || S > nchunks) S = 1;
   int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
   if (S * QG > 8) QG = 1;
-  const int terms = net->opt[IRBFN_OPT_FWD_F16_TERMS] == 1 ? 1 : 3;
+  const int ot = net->opt[IRBFN_OPT_FWD_F16_TERMS];
+  const int terms = (ot == 1 || ot == 2) ? ot : 3;           // 1: plain f16, 2: plain bf16 (both reporting only), 3: pairs
   return launch_forward_f16(net, x, out, B, S, QG, terms, s);
 }
 

@@ -53,8 +53,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int kF16Chunk = 32;                    // centres per chunk = MFMA K
 constexpr int kF16WBytes = 4 * 16 * 8 * 2;       // one W part of a chunk: [g][n][8] halfs = 1 KiB
 constexpr int f16_rf(int DC) { return DC <= 3 ? 4 : (DC <= 7 ? 8 : 12); }    // floats per centre record
-constexpr int f16_chunk_bytes(int DC, int NT = 1) { return kF16Chunk * f16_rf(DC) * 4 + NT * 2 * kF16WBytes; }
-// chunk image: rec[32][RF] floats, then per column tile ct < NT: Whi[ct] (1 KiB), Wlo[ct] (1 KiB)
+constexpr int f16_chunk_bytes(int DC, int NT = 1) { return kF16Chunk * f16_rf(DC) * 4 + NT * 2 * kF16WBytes + (NT == 1 ? kF16WBytes : 0); }
+// chunk image: rec[32][RF] floats, then per column tile ct < NT: Whi[ct] (1 KiB), Wlo[ct] (1 KiB); narrow nets (NT = 1)
+// carry a third part Wbf (1 KiB): the same scaled weights rounded to bf16, for the plain-bf16 variant of config 5
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
 
 struct F16Args {
   const float* __restrict__ x;            // [B][Dreal]
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
   if (idx >= nchunks * kF16Chunk) return;
   const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
   const int n = idx;                                         // centre index (R == 1: n == k)
-  const size_t cb = (size_t)kF16Chunk * RF * 4 + (size_t)NT * 2 * kF16WBytes;
+  const size_t cb = (size_t)kF16Chunk * RF * 4 + (size_t)NT * 2 * kF16WBytes + (NT == 1 ? kF16WBytes : 0);
   unsigned char* p = img + (size_t)c * cb;
   float* rec = reinterpret_cast<float*>(p) + kk * RF;
   const bool real = n < N;
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
       split_static_f16(w, h, l);
       wh[(g * 16 + oo) * 8 + j] = h;
       wl[(g * 16 + oo) * 8 + j] = l;
+      if (NT == 1) reinterpret_cast<__bf16*>(wl + kF16WBytes / 2)[(g * 16 + oo) * 8 + j] = (__bf16)(w * kWScale);
     }
   }
 }
@@ -145,8 +149,17 @@ __device__ __forceinline__ float f16_arg(float r2, float sc) {
 #ifndef IRBFN_K1H_MIN_WAVES
 #define IRBFN_K1H_MIN_WAVES 2      // waves per SIMD the register allocation must allow (512 threads = 2 per block)
 #endif
-template <int DC, int BC, int TERMS>
+template <bool BF>
+__device__ __forceinline__ f4_t mfma_16x16x32(h8_t av, h8_t bv, f4_t c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, av), __builtin_bit_cast(bf8_t, bv), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+}
+
+// TERMS: 3 = (hi, lo) f16 pairs (the product path); 1 = plain f16 operands; BF (with TERMS = 1) = plain bf16 operands --
+// the two reduced-precision variants BASELINE config 5 asks to report, reachable only through an explicit option.
+template <int DC, int BC, int TERMS, bool BF = false>
 __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(const F16Args a) {
+  static_assert(!BF || TERMS == 1, "bf16 operands: single product");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RF = f16_rf(DC);
   constexpr int RECB = kF16Chunk * RF * 4;                   // record bytes per chunk
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
         __builtin_amdgcn_global_load_lds((gptr_t)(gp + v * 1024),
                                          (lptr_t)(dst + v * 1024), 16, 0, 0);
 #pragma unroll
-    for (int v = 0; v < WB / 1024; ++v)
-      __builtin_amdgcn_global_load_lds((gptr_t)(gp + RECB + v * 1024),
+    for (int v = 0; v < WB / 1024; ++v)          // bf16 variant: the third W part lands in the "hi" slot of the ring
+      __builtin_amdgcn_global_load_lds((gptr_t)(gp + RECB + (BF ? 2 * kF16WBytes : 0) + v * 1024),
                                        (lptr_t)(dst + RECB + v * 1024), 16, 0, 0);
   };
 
@@ -228,8 +241,8 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
       if (m < TERMS) {
         const h8_t av = (m == 1) ? al[t] : ah[t];
         const h8_t bv = (m == 2) ? bl : bh;
-        if (m == 0 || (m == 1 && !IRBFN_K1H_PHI_LOS)) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
-        else acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acl[t], 0, 0, 0);
+        if (m == 0 || (m == 1 && !IRBFN_K1H_PHI_LOS)) acc[t] = mfma_16x16x32<BF>(av, bv, acc[t]);
+        else acl[t] = mfma_16x16x32<BF>(av, bv, acl[t]);
       }
     }
     trans_block<BC, 16>(t16);                                // P = 2^kPhiExp * phi for the step's 16 pairs
@@ -237,8 +250,14 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
     for (int t = 0; t < 2; ++t) {
       unsigned wh[4], wl[4];                                 // 4 packed f16 pairs each = one MFMA A operand
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        split_pair_f16<TERMS, IRBFN_K1H_PHI_LOS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+      for (int jj = 0; jj < 4; ++jj) {
+        if constexpr (BF) {
+          wh[jj] = __builtin_bit_cast(unsigned, bf2_t{(__bf16)t16[t * 8 + 2 * jj], (__bf16)t16[t * 8 + 2 * jj + 1]});
+          wl[jj] = 0u;
+        } else {
+          split_pair_f16<TERMS, IRBFN_K1H_PHI_LOS>(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+        }
+      }
       ah[t] = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
       al[t] = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
     }
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
   // drain the deferred MFMAs of the last step
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t], 0, 0, 0);
+    acc[t] = mfma_16x16x32<BF>(ah[t], bh, acc[t]);
     if constexpr (TERMS >= 2 && IRBFN_K1H_PHI_LOS) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acl[t], 0, 0, 0);
     if constexpr (TERMS >= 2 && !IRBFN_K1H_PHI_LOS) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t], 0, 0, 0);
     if constexpr (TERMS >= 3) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acl[t], 0, 0, 0);
@@ -567,12 +586,12 @@ static int launch_forward_f16_wide(irbfn_net* net, const float* x, float* out, i
   return rc;
 }
 
-template <int DC, int TERMS>
+template <int DC, int TERMS, bool BF = false>
 static int launch_f16_bc(const F16Args& a, int bc, int grid, int block, size_t lds, hipStream_t s) {
   switch (bc) {
-    case BC_GAUSS: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_GAUSS, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
-    case BC_IQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IQ, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
-    case BC_IMQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IMQ, TERMS>), dim3(grid), dim3(block), lds, s, a); break;
+    case BC_GAUSS: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_GAUSS, TERMS, BF>), dim3(grid), dim3(block), lds, s, a); break;
+    case BC_IQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IQ, TERMS, BF>), dim3(grid), dim3(block), lds, s, a); break;
+    case BC_IMQ: hipLaunchKernelGGL((rbf_fwd_f16mfma<DC, BC_IMQ, TERMS, BF>), dim3(grid), dim3(block), lds, s, a); break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
@@ -581,6 +600,7 @@ static int launch_f16_bc(const F16Args& a, int bc, int grid, int block, size_t l
 
 template <int DC>
 static int launch_f16_dc(const F16Args& a, int terms, int bc, int grid, int block, size_t lds, hipStream_t s) {
+  if (terms == 2) return launch_f16_bc<DC, 1, true>(a, bc, grid, block, lds, s);       // plain bf16 operands
   return terms == 1 ? launch_f16_bc<DC, 1>(a, bc, grid, block, lds, s) : launch_f16_bc<DC, 3>(a, bc, grid, block, lds, s);
 }
 
@@ -610,8 +630,8 @@ int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, in
     default: rc = IRBFN_ERR_UNSUPPORTED;
   }
   if (rc == IRBFN_OK) {
-    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16mfma<D=%d,BC=%d,TERMS=%d,S=%d,QG=%d>", net->DC,
-             net->bclass, terms == 1 ? 1 : 3, S, QG);
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16mfma<D=%d,BC=%d,TERMS=%s,S=%d,QG=%d>", net->DC,
+             net->bclass, terms == 1 ? "1" : (terms == 2 ? "1,BF16" : "3"), S, QG);
     net->last_grid = grid;
     net->last_block = waves * 64;
   }

@@ -73,6 +73,10 @@ def test_f16mfma_cfg2_accuracy_and_agreement(gpu):
     assert "TERMS=1" in nm
     e1 = (np.abs(g1 - ref) / scale).max()
     assert 3e-6 < e1 <= 2e-3, e1
+    gb, nm = _run(net, params, x, fwd_f16_terms=2)                     # plain bf16 operands (BASELINE config 5's "bf16")
+    assert "BF16" in nm
+    eb = (np.abs(gb - ref) / scale).max()
+    assert e1 < eb <= 2e-2, (e1, eb)
 
 
 @pytest.mark.parametrize("run", ["dnmpc_1regions_newdata_oldintloss_nomirror_highk",
