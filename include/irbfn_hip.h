@@ -265,11 +265,28 @@ int irbfn_intersect_point(const double* points_dev, const double* trajectory_dev
  * tanh indicator.  irbfn_cluster_gate: logits = x Wc + bc [B,R] (second output of the reference module) and
  * gamma = softmax(logits) [B,R]; wc [D,R], bc [R] device pointers.  irbfn_net_forward_gamma: the fused
  * sum_r gamma[b,r] phi[b,r,k] -> Dense forward (model.py:405-412) with caller-provided gamma_dev [B,R], on a
- * descriptor created with R regions (its own gate tables are ignored).  Forward only. */
+ * descriptor created with R regions (its own gate tables are ignored). */
 int irbfn_cluster_gate(const float* x_dev, const float* wc_dev, const float* bc_dev, float* logits_dev, float* gamma_dev,
                        int64_t B, int D, int R, void* stream);
 int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, float* out_dev, int64_t B,
                             void* stream);
+
+/* VJP of ClusterWCRBFNet (the reference trains it: scripts/train_nmpc_frenet.py:424-453).
+ * irbfn_net_vjp_gamma: irbfn_net_vjp with caller-provided region weights gamma_dev [B,R] (the softmax gate) instead of
+ *   the tanh tables, plus -- if dgamma_dev is not NULL -- the cotangent of those weights,
+ *   dgamma[b,r] = sum_k (gout W^T)[b,k] phi[b,r,k]   (O <= 16).
+ * irbfn_cluster_gate_vjp: softmax + Dense backward of the gate (model.py:402-404): dlogits = gamma * (dgamma -
+ *   <gamma, dgamma>) [+ glogits_dev, the direct cotangent of the logits; may be NULL] -> g_wc [D,R], g_bc [R];
+ *   dlogits_dev [B,R] is scratch / output.
+ * irbfn_softmax_xent: optax.softmax_cross_entropy(logits, labels).mean() (train_nmpc_frenet.py:431) -> loss (added to
+ *   *loss_dev if accumulate != 0) and glogits = d loss / d logits; partials_dev: irbfn_train_loss_partials() floats. */
+int irbfn_net_vjp_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, const float* gout_dev,
+                        float* g_centers_dev, float* g_log_sigs_dev, float* g_kernel_dev, float* g_bias_dev, float* dgamma_dev,
+                        int64_t B, void* workspace_dev, int64_t workspace_bytes, void* stream);
+int irbfn_cluster_gate_vjp(const float* x_dev, const float* gamma_dev, const float* dgamma_dev, const float* glogits_dev,
+                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R, void* stream);
+int irbfn_softmax_xent(const float* logits_dev, const float* labels_dev, float* glogits_dev, float* loss_dev,
+                       float* partials_dev, int accumulate, int64_t B, int R, void* stream);
 
 /* Dense head of DeeperWCRBFNet (src/irbfn_mpc/model.py:201-289; the model of IRBFNFrenetPlanner with
  * deeper=True, src/irbfn_mpc/irbfn_planner.py:286-298):  out = linear(relu(linear_pre2(relu(h1)))) with

@@ -188,6 +188,34 @@ int irbfn_net_vjp(irbfn_net* net, const float* x_dev, const float* gout_dev, flo
                     workspace_dev, workspace_bytes, as_stream(stream));
 }
 
+int irbfn_net_vjp_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, const float* gout_dev,
+                        float* g_centers_dev, float* g_log_sigs_dev, float* g_kernel_dev, float* g_bias_dev, float* dgamma_dev,
+                        int64_t B, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+  if (!net || B < 0 || !g_centers_dev || !g_log_sigs_dev || !g_kernel_dev || !g_bias_dev) return IRBFN_ERR_BAD_ARG;
+  if (B > 0 && (!x_dev || !gout_dev || !gamma_dev)) return IRBFN_ERR_BAD_ARG;
+  if (!net->has_params) return IRBFN_ERR_NO_PARAMS;
+  if (workspace_bytes < vjp_workspace_bytes(net, B) || (!workspace_dev && vjp_workspace_bytes(net, B) > 0))
+    return IRBFN_ERR_BAD_ARG;
+  int rc = launch_vjp(net, x_dev, gout_dev, g_centers_dev, g_log_sigs_dev, g_kernel_dev, g_bias_dev, B, workspace_dev,
+                      workspace_bytes, as_stream(stream), B > 0 ? gamma_dev : nullptr);
+  if (rc == IRBFN_OK && dgamma_dev) rc = launch_dgamma(net, x_dev, gout_dev, dgamma_dev, B, as_stream(stream));
+  return rc;
+}
+
+int irbfn_cluster_gate_vjp(const float* x_dev, const float* gamma_dev, const float* dgamma_dev, const float* glogits_dev,
+                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R, void* stream) {
+  if (B < 0 || D < 1 || R < 1 || !g_wc_dev || !g_bc_dev) return IRBFN_ERR_BAD_ARG;
+  if (B > 0 && (!x_dev || !gamma_dev || !dgamma_dev || !dlogits_dev)) return IRBFN_ERR_BAD_ARG;
+  return launch_cluster_gate_vjp(x_dev, gamma_dev, dgamma_dev, glogits_dev, dlogits_dev, g_wc_dev, g_bc_dev, B, D, R,
+                                 as_stream(stream));
+}
+
+int irbfn_softmax_xent(const float* logits_dev, const float* labels_dev, float* glogits_dev, float* loss_dev,
+                       float* partials_dev, int accumulate, int64_t B, int R, void* stream) {
+  if (B < 1 || R < 1 || !logits_dev || !labels_dev || !glogits_dev || !loss_dev || !partials_dev) return IRBFN_ERR_BAD_ARG;
+  return launch_softmax_xent(logits_dev, labels_dev, glogits_dev, loss_dev, partials_dev, accumulate, B, R, as_stream(stream));
+}
+
 int irbfn_rollout_state_dim(int mode) {
   const int s = rollout_state_dim(mode);
   return s < 0 ? IRBFN_ERR_BAD_ARG : s;

@@ -327,6 +327,176 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   return p;
 }
 
+// ---- ClusterWCRBFNet (src/irbfn_mpc/model.py:341-414): cotangent of the region weights ------------------------------
+// d gamma[b,r] = sum_k hbar[b,k] phi[b,r,k],  hbar = g W^T  (the path from `out` back to the softmax gate; the tanh
+// gate of WCRBFNet has no parameters, so K2 never needs it).  One lane per query, one wave per (64 queries, region):
+// the region's K centre records are wave-uniform scalar streams, g[b,:] sits in registers.
+template <int D, int OP>
+__global__ __launch_bounds__(64) void dgamma_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                    const float* __restrict__ rec, float* __restrict__ dgamma, long B,
+                                                    int Dreal, int O, int K, int R, int S, int bclass, int basis) {
+  const int lane = threadIdx.x, r = blockIdx.y;
+  const long b = (long)blockIdx.x * kWave + lane;
+  const long bb = b < B ? b : B - 1;
+  float xq[D], gq[OP];
+#pragma unroll
+  for (int j = 0; j < D; ++j) xq[j] = j < Dreal ? x[bb * Dreal + j] : 0.0f;
+#pragma unroll
+  for (int o = 0; o < OP; ++o) gq[o] = o < O ? g[bb * O + o] : 0.0f;
+  float acc = 0.0f;
+  const float* rp = rec + (size_t)r * K * S;
+  for (int k = 0; k < K; ++k, rp += S) {
+    float r2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float d = xq[j] - rp[j];
+      r2 = __builtin_fmaf(d, d, r2);
+    }
+    float phi;
+    switch (bclass) {
+      case BC_GAUSS: phi = basis_from_r2<BC_GAUSS>(r2, rp[D], basis); break;
+      case BC_IQ: phi = basis_from_r2<BC_IQ>(r2, rp[D], basis); break;
+      case BC_IMQ: phi = basis_from_r2<BC_IMQ>(r2, rp[D], basis); break;
+      default: phi = basis_from_r2<BC_GENERIC>(r2, rp[D], basis); break;
+    }
+    float hb = 0.0f;
+#pragma unroll
+    for (int o = 0; o < OP; ++o) hb = __builtin_fmaf(gq[o], rp[D + 1 + o], hb);
+    acc = __builtin_fmaf(hb, phi, acc);
+  }
+  if (b < B) dgamma[b * R + r] = acc;
+}
+
+template <int D>
+static int launch_dgamma_d(const irbfn_net* net, const float* x, const float* g, float* dgamma, int64_t B, hipStream_t s) {
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave), net->R), block(kWave);
+#define IRBFN_DG(OPV)                                                                                                \
+  case OPV:                                                                                                          \
+    hipLaunchKernelGGL((dgamma_kernel<D, OPV>), grid, block, 0, s, x, g, net->rec, dgamma, (long)B, net->D, net->O,  \
+                       net->K, net->R, net->S, net->bclass, net->basis);                                             \
+    break;
+  switch (net->OP) {
+    IRBFN_DG(2) IRBFN_DG(4) IRBFN_DG(5) IRBFN_DG(8) IRBFN_DG(10) IRBFN_DG(16)
+    default: return IRBFN_ERR_UNSUPPORTED;       // O <= 16
+  }
+#undef IRBFN_DG
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+int launch_dgamma(irbfn_net* net, const float* x, const float* gout, float* dgamma, int64_t B, hipStream_t s) {
+  if (B == 0) return IRBFN_OK;
+  switch (net->DC) {
+    case 3: return launch_dgamma_d<3>(net, x, gout, dgamma, B, s);
+    case 4: return launch_dgamma_d<4>(net, x, gout, dgamma, B, s);
+    case 7: return launch_dgamma_d<7>(net, x, gout, dgamma, B, s);
+    case 8: return launch_dgamma_d<8>(net, x, gout, dgamma, B, s);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+// softmax backward of the cluster gate (model.py:402-404): d logits = gamma * (d gamma - sum_s gamma_s d gamma_s)
+// [+ the direct cotangent of the logits, e.g. of the cluster cross-entropy], one thread per query
+__global__ __launch_bounds__(256) void cluster_dlogits_kernel(const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                              const float* __restrict__ glogits, float* __restrict__ dlogits,
+                                                              long B, int R) {
+  const long b = (long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float dot = 0.0f;
+  for (int r = 0; r < R; ++r) dot = __builtin_fmaf(gamma[b * R + r], dgamma[b * R + r], dot);
+  for (int r = 0; r < R; ++r) {
+    float v = gamma[b * R + r] * (dgamma[b * R + r] - dot);
+    if (glogits) v += glogits[b * R + r];
+    dlogits[b * R + r] = v;
+  }
+}
+
+// d Wc[d,r] = sum_b x[b,d] dlogits[b,r] (d < D), d bc[r] = sum_b dlogits[b,r] (d == D): one block per output, fixed tree
+__global__ __launch_bounds__(256) void cluster_dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dlogits,
+                                                                float* __restrict__ g_wc, float* __restrict__ g_bc, long B,
+                                                                int D, int R) {
+  __shared__ float sm[256];
+  const int d = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+  float s = 0.0f;
+  for (long b = t; b < B; b += 256) s = __builtin_fmaf(d < D ? x[b * D + d] : 1.0f, dlogits[b * R + r], s);
+  sm[t] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) sm[t] += sm[t + w];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (d < D) g_wc[d * R + r] = sm[0];
+    else g_bc[r] = sm[0];
+  }
+}
+
+int launch_cluster_gate_vjp(const float* x, const float* gamma, const float* dgamma, const float* glogits, float* dlogits,
+                            float* g_wc, float* g_bc, int64_t B, int D, int R, hipStream_t s) {
+  if (B == 0) {
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_wc, 0, (size_t)D * R * sizeof(float), s));
+    IRBFN_HIP_CHECK(hipMemsetAsync(g_bc, 0, (size_t)R * sizeof(float), s));
+    return IRBFN_OK;
+  }
+  hipLaunchKernelGGL(cluster_dlogits_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, gamma, dgamma, glogits, dlogits,
+                     (long)B, R);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(cluster_dense_bwd_kernel, dim3(D + 1, R), dim3(256), 0, s, x, dlogits, g_wc, g_bc, (long)B, D, R);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// optax.softmax_cross_entropy(logits, labels).mean() (scripts/train_nmpc_frenet.py:431) and its cotangent of the logits:
+// loss_b = -sum_r labels[b,r] log_softmax(logits)[b,r];  d loss / d logits = (softmax * sum_r labels - labels) / B.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                           float* __restrict__ glogits, float* __restrict__ loss_part, long B,
+                                                           int R) {
+  __shared__ float sm[256];
+  float lsum = 0.0f;
+  const float invB = 1.0f / (float)B;
+  for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
+    float mx = -INFINITY;
+    for (int r = 0; r < R; ++r) mx = fmaxf(mx, logits[b * R + r]);
+    float se = 0.0f, sl = 0.0f;
+    for (int r = 0; r < R; ++r) { se += expf(logits[b * R + r] - mx); sl += labels[b * R + r]; }
+    const float lse = mx + logf(se);
+    for (int r = 0; r < R; ++r) {
+      const float lp = logits[b * R + r] - lse;
+      lsum += -labels[b * R + r] * lp * invB;
+      glogits[b * R + r] = (expf(lp) * sl - labels[b * R + r]) * invB;
+    }
+  }
+  sm[threadIdx.x] = lsum;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(256) void xent_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+  __shared__ float sm[256];
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + sm[0] : sm[0];
+}
+
+int launch_softmax_xent(const float* logits, const float* labels, float* glogits, float* loss, float* partials, int accumulate,
+                        int64_t B, int R, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(256), dim3(256), 0, s, logits, labels, glogits, partials, (long)B, R);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, s, partials, 256, loss, accumulate);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
 int64_t vjp_workspace_bytes(const irbfn_net* net, int64_t B) {
   if (B <= 0) return 0;
   return (int64_t)make_plan(net, B).total;
@@ -381,7 +551,8 @@ static int launch_vjp_d(const VjpArgs& a, int OP, int bc, bool gated, dim3 grid,
 }
 
 int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_centers, float* g_log_sigs,
-               float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s) {
+               float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s,
+               const float* gamma_ext) {
   (void)ws_bytes;
   if (net->bclass == BC_GENERIC && net->basis != IRBFN_MULTIQUADRIC && net->basis != IRBFN_QUADRATIC)
     return IRBFN_ERR_UNSUPPORTED;   // hand VJP exists for the d^2-only bases
@@ -393,7 +564,8 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     IRBFN_HIP_CHECK(hipMemsetAsync(g_bias, 0, (size_t)net->O * sizeof(float), s));
     return IRBFN_OK;
   }
-  const VjpPlan p = make_plan(net, B);
+  VjpPlan p = make_plan(net, B);
+  if (gamma_ext) p.use_h = false;                // caller-provided region weights (ClusterWCRBFNet): the gated K2
   char* base = static_cast<char*>(ws);
   float* gamma = reinterpret_cast<float*>(base + p.off_gamma);
   float* part = reinterpret_cast<float*>(base + p.off_part);
@@ -427,11 +599,11 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   int rc = IRBFN_OK;
 
   VjpArgs a;
-  a.qrec = qrec; a.gamma = gamma; a.rec = net->rec; a.sig2 = net->sig2; a.part = part;
+  a.qrec = qrec; a.gamma = gamma_ext ? gamma_ext : gamma; a.rec = net->rec; a.sig2 = net->sig2; a.part = part;
   a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.N = net->N; a.K = net->K; a.R = net->R; a.S = net->S;
   a.basis = net->basis; a.Npad = p.Npad; a.per_wave = p.per_wave; a.gscale = gauss_scale(net->basis);
   const dim3 grid(p.groups, p.QSB);
-  const bool gated = net->R > 1;
+  const bool gated = net->R > 1 || gamma_ext != nullptr;
   switch (net->DC) {
     case 3: rc = launch_vjp_d<3>(a, net->OP, net->bclass, gated, grid, s); break;
     case 4: rc = launch_vjp_d<4>(a, net->OP, net->bclass, gated, grid, s); break;

@@ -387,8 +387,9 @@ class ClusterWCRBFNet:
     """``ClusterWCRBFNet`` of the reference (src/irbfn_mpc/model.py:341-414): R RBF layers mixed by a learned
     softmax gate ``softmax(Dense(R)(x))`` instead of the tanh indicator.  Parameter pytree: ``{"rbf_list":
     {centers[R,K,D], log_sigs[R,K]}, "linear": {kernel[K,O], bias[O]}, "cluster": {kernel[D,R], bias[R]}}``.
-    ``apply`` returns ``(out, logits)`` like the reference module.  Forward only; no trained checkpoint of this
-    variant survives in the reference (.MISSING_LARGE_BLOBS) -> parity against the oracle restatement only."""
+    ``apply`` returns ``(out, logits)`` like the reference module; ``vjp`` is the parameter VJP of both outputs (what
+    ``train_step_fullint_withcluster`` differentiates, scripts/train_nmpc_frenet.py:424-453).  No trained checkpoint
+    of this variant survives in the reference (.MISSING_LARGE_BLOBS) -> parity against the oracle restatement only."""
 
     def __init__(self, in_features, out_features, num_kernels, basis_func, num_regions, **_unused):
         self.in_features, self.out_features = int(in_features), int(out_features)
@@ -419,6 +420,62 @@ class ClusterWCRBFNet:
         st = lib.irbfn_net_forward_gamma(self.stage._handle(torch), _ptr(xd), _ptr(gamma), _ptr(out), B, _stream_ptr(torch))
         _lib.check(st, "irbfn_net_forward_gamma")
         return like_input(out, x, torch), like_input(logits, x, torch)
+
+    def vjp(self, params: dict, x, gout, glogits=None, out: Optional[dict] = None) -> dict:
+        """Parameter VJP of ``apply``: cotangents gout[B,O] of ``out`` and (optionally) glogits[B,R] of ``logits`` ->
+        gradient pytree with the structure of ``params`` (rbf_list / linear / cluster).  The gate is recomputed (one
+        [B,D]x[D,R] pass), K2 runs with the softmax weights, the cotangent of those weights comes from
+        ``irbfn_net_vjp_gamma`` and goes back through softmax + Dense in ``irbfn_cluster_gate_vjp``."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        D, R, O, K = self.in_features, self.num_regions, self.out_features, self.stage.num_kernels
+        if O > 16:
+            raise ValueError("ClusterWCRBFNet.vjp supports out_features <= 16 (the reference trains it with 10)")
+        self.stage.bind({"rbf_list": p["rbf_list"], "linear": p["linear"]})
+        xd, gd = to_device_f32(x, torch), to_device_f32(gout, torch)
+        B = xd.shape[0]
+        if tuple(xd.shape) != (B, D) or tuple(gd.shape) != (B, O):
+            raise ValueError(f"x must be [B, {D}] and gout [B, {O}]")
+        gl_in = None
+        if glogits is not None:
+            gl_in = to_device_f32(glogits, torch)
+            if tuple(gl_in.shape) != (B, R):
+                raise ValueError(f"glogits must be [B, {R}]")
+        dev = xd.device
+        shapes = {"centers": (R, K, D), "log_sigs": (R, K), "kernel": (K, O), "bias": (O,), "ckernel": (D, R), "cbias": (R,)}
+        if out is not None:
+            o = _inner(out)
+            leaves = {"centers": o["rbf_list"]["centers"], "log_sigs": o["rbf_list"]["log_sigs"], "kernel": o["linear"]["kernel"],
+                      "bias": o["linear"]["bias"], "ckernel": o["cluster"]["kernel"], "cbias": o["cluster"]["bias"]}
+            for n, t in leaves.items():
+                if tuple(t.shape) != shapes[n] or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                    raise ValueError("vjp out= leaves must be contiguous float32 cuda tensors of the parameter shapes")
+        else:
+            leaves = {n: torch.empty(shp, dtype=torch.float32, device=dev) for n, shp in shapes.items()}
+        wc, bc = to_device_f32(p["cluster"]["kernel"], torch), to_device_f32(p["cluster"]["bias"], torch)
+        logits = torch.empty((B, R), dtype=torch.float32, device=dev)
+        gamma = torch.empty((B, R), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((B, R), dtype=torch.float32, device=dev)
+        stream = _stream_ptr(torch)
+        _lib.check(lib.irbfn_cluster_gate(_ptr(xd), _ptr(wc), _ptr(bc), _ptr(logits), _ptr(gamma), B, D, R, stream),
+                   "irbfn_cluster_gate")
+        h = self.stage._handle(torch)
+        nbytes = int(lib.irbfn_net_vjp_workspace_bytes(h, B))
+        ws = self.stage._vjp_ws.get(dev.index)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=dev)
+            self.stage._vjp_ws[dev.index] = ws
+        st = lib.irbfn_net_vjp_gamma(h, _ptr(xd), _ptr(gamma), _ptr(gd), _ptr(leaves["centers"]), _ptr(leaves["log_sigs"]),
+                                     _ptr(leaves["kernel"]), _ptr(leaves["bias"]), _ptr(dgamma), B, _ptr(ws), nbytes, stream)
+        _lib.check(st, "irbfn_net_vjp_gamma")
+        st = lib.irbfn_cluster_gate_vjp(_ptr(xd), _ptr(gamma), _ptr(dgamma), _ptr(gl_in) if gl_in is not None else None,
+                                        _ptr(logits), _ptr(leaves["ckernel"]), _ptr(leaves["cbias"]), B, D, R, stream)
+        _lib.check(st, "irbfn_cluster_gate_vjp")
+        conv = (lambda t: t) if out is not None else (lambda t: like_input(t, x, torch))
+        return {"params": {"rbf_list": {"centers": conv(leaves["centers"]), "log_sigs": conv(leaves["log_sigs"])},
+                           "linear": {"kernel": conv(leaves["kernel"]), "bias": conv(leaves["bias"])},
+                           "cluster": {"kernel": conv(leaves["ckernel"]), "bias": conv(leaves["cbias"])}}}
 
 
 class _State:

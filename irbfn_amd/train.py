@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib, distributed
 from .dynamics import _dyn
-from .model import WCRBFNet, _ptr, _stream_ptr, to_device_f32
+from .model import ClusterWCRBFNet, WCRBFNet, _ptr, _stream_ptr, to_device_f32
 
 
 class TrainState:
@@ -62,9 +62,46 @@ class TrainState:
                 int(self.step.item()))
 
 
-def _backward_and_update(state: TrainState, x, gy, torch, lib):
+class ClusterTrainState(TrainState):
+    """TrainState of a ``ClusterWCRBFNet`` (scripts/train_nmpc_frenet.py:424-453): the flat buffers hold the four
+    leaves of the RBF stage followed by ``cluster.kernel`` [D,R] and ``cluster.bias`` [R]."""
+
+    def __init__(self, net: ClusterWCRBFNet, flat, lr, max_grad_norm, b1, b2, eps):
+        self._cluster = net
+        super().__init__(net.stage, flat[:distributed.flat_param_count(net.stage)], lr, max_grad_norm, b1, b2, eps)
+        import torch
+        self.net = net
+        self.flat = flat
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.gbuf = torch.zeros(flat.numel() + 2, dtype=torch.float32, device=flat.device)
+        self.g = self.gbuf[:flat.numel()]
+        self.params, self.grads = self._views(self.flat), self._views(self.g)
+        self.apply_fn = net.apply
+
+    def _views(self, flat) -> dict:
+        n = distributed.flat_param_count(self._cluster.stage)
+        D, R = self._cluster.in_features, self._cluster.num_regions
+        p = distributed.unflatten_params(self._cluster.stage, flat[:n])
+        p["params"]["cluster"] = {"kernel": flat[n:n + D * R].view(D, R), "bias": flat[n + D * R:n + D * R + R].view(R)}
+        return p
+
+    @classmethod
+    def create(cls, net: ClusterWCRBFNet, params: dict, lr: float = 1e-3, max_grad_norm: float = 1.0,
+               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> "ClusterTrainState":
+        torch = _lib.require_gpu()
+        p = params["params"] if "params" in params else params
+        stage = distributed.flatten_params(distributed.params_to_device(p))
+        flat = torch.cat([stage, to_device_f32(p["cluster"]["kernel"], torch).reshape(-1),
+                          to_device_f32(p["cluster"]["bias"], torch).reshape(-1)]).clone()
+        return cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+
+    def opt_state(self):
+        return self._views(self.m), self._views(self.v), int(self.step.item())
+
+
+def _backward_and_update(state: TrainState, x, gy, torch, lib, **vjp_kw):
     """VJP -> [all-reduce] -> clip + Adam.  Returns the loss of the (global) batch, a 1-element device tensor."""
-    state.net.vjp(state.params, x, gy, out=state.grads)
+    state.net.vjp(state.params, x, gy, out=state.grads, **vjp_kw)
     loss = state.loss.clone()
     if distributed.is_dist() and torch.distributed.get_world_size() > 1:
         # every rank normalised its seeds and its loss by its LOCAL batch: weight both by B_local, sum over the
@@ -81,7 +118,7 @@ def _backward_and_update(state: TrainState, x, gy, torch, lib):
                                   _ptr(state.partials), _stream_ptr(torch))
     _lib.check(st, "irbfn_adam_clip_step")
     # the parameter leaves were updated in place behind torch's back: re-bind on the next apply
-    state.net._bound_fp.pop(torch.cuda.current_device(), None)
+    getattr(state.net, "stage", state.net)._bound_fp.pop(torch.cuda.current_device(), None)
     return loss
 
 
@@ -135,6 +172,30 @@ def train_step_frenet_fullint(state: TrainState, x, y, dyn_params, clip_tie: flo
                                               _ptr(state.loss), _ptr(state.partials), B, 8, O // 2, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_frenet_fullint")
     return state, _backward_and_update(state, xd, gy, torch, lib)
+
+
+def train_step_fullint_withcluster(state: ClusterTrainState, x, y, cluster_ids, dyn_params, clip_tie: float = 0.5):
+    """``train_step_fullint_withcluster`` (scripts/train_nmpc_frenet.py:424-453): the Frenet full-integration loss plus
+    ``optax.softmax_cross_entropy(logits, cluster_ids).mean()`` on the gate of a ClusterWCRBFNet.  x [B,8], y [B,2T],
+    cluster_ids [B,R] (one-hot or soft labels) -> (state, loss[1] on device)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    xd, yd, cd = to_device_f32(x, torch), to_device_f32(y, torch), to_device_f32(cluster_ids, torch)
+    B, O = yd.shape
+    net = state.net
+    if xd.shape[1] != 8 or O != net.out_features or O % 2 or O // 2 > 16 or tuple(cd.shape) != (B, net.num_regions):
+        raise ValueError("train_step_fullint_withcluster needs x [B,8], y [B, out_features = 2T] (T <= 16), cluster_ids [B,R]")
+    y_pred, logits = net.apply(state.params, xd)
+    gy, glogits = torch.empty_like(y_pred), torch.empty_like(logits)
+    keep, pp = _dyn(dyn_params)
+    stream = _stream_ptr(torch)
+    st = lib.irbfn_train_seeds_frenet_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy),
+                                              _ptr(state.loss), _ptr(state.partials), B, 8, O // 2, stream)
+    _lib.check(st, "irbfn_train_seeds_frenet_fullint")
+    st = lib.irbfn_softmax_xent(_ptr(logits), _ptr(cd), _ptr(glogits), _ptr(state.loss), _ptr(state.partials), 1, B,
+                                net.num_regions, stream)
+    _lib.check(st, "irbfn_softmax_xent")
+    return state, _backward_and_update(state, xd, gy, torch, lib, glogits=glogits)
 
 
 def train_epoch(state: TrainState, table, batch_size: int, only_onestep: bool = False, dyn_params=None):

@@ -274,20 +274,47 @@ def deeper_wcrbfnet_apply(cfg: dict, params: dict, x):
 
 
 def cluster_wcrbfnet_apply(cfg: dict, params: dict, x):
-    """ClusterWCRBFNet.__call__ -- src/irbfn_mpc/model.py:393-414: (out, logits)."""
+    """ClusterWCRBFNet.__call__ -- src/irbfn_mpc/model.py:393-414: (out, logits).  numpy (float64) or torch tensors
+    (autograd: the oracle of the cluster VJP)."""
     p = params["params"] if "params" in params else params
-    x = np.asarray(x, np.float64)
-    c = np.asarray(p["rbf_list"]["centers"], np.float64)            # [R,K,D]
-    ls = np.asarray(p["rbf_list"]["log_sigs"], np.float64)          # [R,K]
-    basis = BASIS[cfg["basis_func"]]
-    d = np.sqrt(((x[:, None, None, :] - c[None]) ** 2).sum(-1)) / np.exp(ls)[None]     # flax_rbf.py:280
-    all_x = basis(d, np)                                            # [B,R,K]                    model.py:400
-    logits = x @ np.asarray(p["cluster"]["kernel"], np.float64) + np.asarray(p["cluster"]["bias"], np.float64)   # :403
-    e = np.exp(logits - logits.max(axis=1, keepdims=True))
-    cluster_ind = e / e.sum(axis=1, keepdims=True)                  # nn.softmax                 :404
-    rbf_out = (cluster_ind[:, :, None] * all_x).sum(axis=1)         # :405-409
-    out = rbf_out @ np.asarray(p["linear"]["kernel"], np.float64) + np.asarray(p["linear"]["bias"], np.float64)  # :412
+    xp = _ns(x)
+    if xp is _NP:
+        x = np.asarray(x, np.float64)
+        p = {g: {n: np.asarray(v, np.float64) for n, v in d.items()} for g, d in p.items()}
+    all_x = rbf_layer(x, p["rbf_list"]["centers"], p["rbf_list"]["log_sigs"], cfg["basis_func"])   # [B,R,K]  model.py:400
+    logits = x @ p["cluster"]["kernel"] + p["cluster"]["bias"]      # nn.Dense(num_regions)      :403
+    if xp is _NP:
+        e = np.exp(logits - logits.max(axis=1, keepdims=True))
+        cluster_ind = e / e.sum(axis=1, keepdims=True)              # nn.softmax                 :404
+    else:
+        import torch
+        cluster_ind = torch.softmax(logits, dim=1)
+    rbf_out = (cluster_ind[:, :, None] * all_x).sum(1)              # :405-409
+    out = rbf_out @ p["linear"]["kernel"] + p["linear"]["bias"]     # :412
     return out, logits
+
+
+def train_fullint_withcluster_loss(cfg, params, x, y, cluster_ids, dyn_params):
+    """scripts/train_nmpc_frenet.py:424-453 -- the Frenet full-integration loss of a ClusterWCRBFNet plus
+    optax.softmax_cross_entropy(logits, cluster_ids).mean() (= -sum(labels * log_softmax(logits), -1).mean(); optax is
+    un-pinned, published definition).  torch tensors (autograd) or numpy."""
+    xp = _ns(x)
+    init = x[:, [0, 0, 1, 2, 3, 5, 6, 7]]                                      # :428
+    y_pred, logits = cluster_wcrbfnet_apply(cfg, params, x)                    # :430
+    if xp is _NP:
+        m = logits.max(axis=1, keepdims=True)
+        logp = logits - m - np.log(np.exp(logits - m).sum(axis=1, keepdims=True))
+        x_pred_u, x_u = np.hstack((init, y_pred)), np.hstack((init, y))
+        absf = np.abs
+    else:
+        import torch
+        logp = torch.log_softmax(logits, dim=1)
+        x_pred_u, x_u = torch.hstack((init, y_pred)), torch.hstack((init, y))
+        absf = lambda t: t.abs()
+    cluster_loss = (-(cluster_ids * logp).sum(1)).mean()                       # :431
+    actual = integrate_frenet_mult(x_u, dyn_params)                            # :439
+    pred = integrate_frenet_mult(x_pred_u, dyn_params)                         # :440
+    return absf(y_pred - y).mean() + absf(pred - actual).mean() + cluster_loss # :433,441,444
 
 
 def wcrbfnet_vjp(cfg: dict, params: dict, x: np.ndarray, gout: np.ndarray):

@@ -201,3 +201,93 @@ def test_deeper_wcrbfnet_vjp_on_the_reference_checkpoint(gpu):
             assert torch.equal(a[grp][name], a2[grp][name])
             e = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300)
             assert e <= 2e-4, (grp, name, e)
+
+
+def _cluster_case(seed, R=11, K=20, O=10, B=400, D=8):
+    rng = np.random.default_rng(seed)
+    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": "gaussian", "num_regions": R}
+    params = {"params": {
+        "rbf_list": {"centers": rng.uniform(-2, 2, size=(R, K, D)).astype(np.float32),
+                     "log_sigs": rng.uniform(0.5, 1.5, size=(R, K)).astype(np.float32)},
+        "linear": {"kernel": (rng.normal(size=(K, O)) * 0.3).astype(np.float32), "bias": (rng.normal(size=(O,)) * 0.1).astype(np.float32)},
+        "cluster": {"kernel": rng.normal(size=(D, R)).astype(np.float32), "bias": rng.normal(size=(R,)).astype(np.float32)}}}
+    x = rng.uniform(-2, 2, size=(B, D)).astype(np.float32)
+    return rng, cfg, params, x
+
+
+CLEAVES = LEAVES + (("cluster", "kernel"), ("cluster", "bias"))
+
+
+def _t64(params, requires_grad=True):
+    return {"params": {k: {n: torch.tensor(np.asarray(v, np.float64), requires_grad=requires_grad) for n, v in d.items()}
+                       for k, d in params["params"].items()}}
+
+
+@pytest.mark.parametrize("R,K,O,B", [(11, 20, 10, 400), (2, 64, 2, 70), (1, 33, 5, 130), (16, 8, 16, 1500)])
+def test_cluster_wcrbfnet_vjp(gpu, R, K, O, B):
+    """ClusterWCRBFNet (model.py:341-414): all six gradient leaves for cotangents of BOTH outputs (out, logits) against
+    torch.autograd of the float64 restatement; without a logits cotangent; deterministic."""
+    from irbfn_amd.model import ClusterWCRBFNet
+    rng, cfg, params, x = _cluster_case(R * 3 + K, R, K, O, B)
+    g = rng.normal(size=(B, O)).astype(np.float32)
+    gl = rng.normal(size=(B, R)).astype(np.float32)
+    net = ClusterWCRBFNet(**cfg)
+    for with_logits in (True, False):
+        a = net.vjp(params, torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda(),
+                    glogits=torch.from_numpy(gl).cuda() if with_logits else None)["params"]
+        a2 = net.vjp(params, torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda(),
+                     glogits=torch.from_numpy(gl).cuda() if with_logits else None)["params"]
+        tp = _t64(params)
+        out, logits = orc.cluster_wcrbfnet_apply(cfg, tp, torch.tensor(x, dtype=torch.float64))
+        obj = (out * torch.tensor(g, dtype=torch.float64)).sum()
+        if with_logits:
+            obj = obj + (logits * torch.tensor(gl, dtype=torch.float64)).sum()
+        obj.backward()
+        for grp, name in CLEAVES:
+            ref, got = tp["params"][grp][name].grad.numpy(), a[grp][name].cpu().numpy()
+            assert torch.equal(a[grp][name], a2[grp][name])
+            e = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300)
+            assert e <= 5e-5, (grp, name, with_logits, e)
+
+
+def test_train_step_fullint_withcluster(gpu):
+    """train_step_fullint_withcluster (scripts/train_nmpc_frenet.py:424-453): loss, the six-leaf gradient (through the
+    softmax gate, the cross-entropy and integrate_frenet_mult) and the clip + Adam update against torch.autograd of
+    the restatement; two steps."""
+    from irbfn_amd.model import ClusterWCRBFNet
+    R, T = 11, 5
+    rng, cfg, params, x = _cluster_case(21, R=R, K=24, O=2 * T, B=300)
+    B = x.shape[0]
+    x[:, 7] = rng.normal(size=B).astype(np.float32) * 0.05
+    x[:, 0] = rng.normal(size=B).astype(np.float32) * 0.2
+    x[:, 2] = rng.uniform(1.0, 6.0, size=B).astype(np.float32)
+    y = np.hstack([rng.normal(size=(B, T)) * 2, rng.normal(size=(B, T)) * 0.5]).astype(np.float32)
+    ids = np.eye(R, dtype=np.float32)[rng.integers(0, R, size=B)]
+    net = ClusterWCRBFNet(**cfg)
+    state = train.ClusterTrainState.create(net, params, lr=1e-3, max_grad_norm=1.0)
+    n = state.flat.numel()
+    flat64 = lambda P: np.concatenate([np.asarray(P["params"][g_][n_], np.float64).reshape(-1) for g_, n_ in CLEAVES])
+    assert n == flat64(params).size
+    m, v, p_ref = np.zeros(n), np.zeros(n), flat64(params)
+    cur = params
+    for t in (1, 2):
+        tp = _t64(cur)
+        loss = orc.train_fullint_withcluster_loss(cfg, tp, torch.tensor(x, dtype=torch.float64), torch.tensor(y, dtype=torch.float64),
+                                                  torch.tensor(ids, dtype=torch.float64), DP)
+        loss.backward()
+        g_ref = np.concatenate([tp["params"][g_][n_].grad.numpy().reshape(-1) for g_, n_ in CLEAVES])
+        p_ref, m, v = orc.adam_update(p_ref, orc.clip_by_global_norm(g_ref, 1.0), m, v, t, lr=1e-3)
+        state, l_gpu = train.train_step_fullint_withcluster(state, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(),
+                                                            torch.from_numpy(ids).cuda(), DP)
+        assert abs(float(l_gpu) - float(loss)) <= 3e-5 * abs(float(loss)), (t, float(l_gpu), float(loss))
+        g_gpu = state.g.cpu().numpy()
+        assert np.abs(g_gpu - g_ref).max() <= 5e-4 * np.abs(g_ref).max(), (t, np.abs(g_gpu - g_ref).max() / np.abs(g_ref).max())
+        assert np.abs(state.flat.cpu().numpy() - p_ref).max() <= 5e-5 + 1e-6 * np.abs(p_ref).max()
+        # next oracle step starts from the oracle's own parameters
+        off, nxt = 0, {"params": {}}
+        for g_, n_ in CLEAVES:
+            shp = np.asarray(params["params"][g_][n_]).shape
+            cnt = int(np.prod(shp))
+            nxt["params"].setdefault(g_, {})[n_] = p_ref[off:off + cnt].reshape(shp)
+            off += cnt
+        cur = nxt
