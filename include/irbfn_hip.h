@@ -116,7 +116,8 @@ typedef enum irbfn_option {
   IRBFN_OPT_VJP_KERNEL = 9,    /* irbfn_vjp_kernel below; default IRBFN_VJP_AUTO */
   IRBFN_OPT_VJP_F16_CT = 10,   /* K2h: 16-centre tiles per wave (2 default, 4) */
   IRBFN_OPT_LDS_PAD = 11,      /* diagnosis: extra dynamic LDS bytes per workgroup of K1h / K2h (lowers occupancy) */
-  IRBFN_OPT_COUNT = 12
+  IRBFN_OPT_FWD_WIDE_PIPE = 12,/* K1h, 16 < O <= 128: 1 (default) pipelined kernel (deferred MFMAs, LDS-DMA ring of three), 0: two-buffer kernel */
+  IRBFN_OPT_COUNT = 13
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
   IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; one region + fast basis + O <= 128: K1h; O > 16: K1m; otherwise K1 */

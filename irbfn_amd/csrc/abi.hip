@@ -69,6 +69,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   net->nsplit = nsplit; net->max_ranges = max_ranges > 0 ? max_ranges : 1; net->n_ranges = n_ranges;
   net->opt[IRBFN_OPT_FWD_SMALL] = 1;
   net->opt[IRBFN_OPT_FWD_F16_TERMS] = 3;
+  net->opt[IRBFN_OPT_FWD_WIDE_PIPE] = 1;
 
   const size_t tab = (size_t)(nsplit > 0 ? nsplit : 1) * net->max_ranges;
   const size_t nr = (size_t)(n_ranges > 0 ? n_ranges : 1) * (nsplit > 0 ? nsplit : 1);
