@@ -20,7 +20,7 @@ ROLLOUT_ST_SELECT, ROLLOUT_ST_KS, ROLLOUT_FULLINT, ROLLOUT_FRENET_LS, ROLLOUT_SP
 
 # irbfn_option / irbfn_fwd_kernel / irbfn_vjp_kernel (include/irbfn_hip.h)
 OPTIONS = {"fwd_kernel": 0, "fwd_small": 1, "fwd_f16_terms": 2, "fwd_f16_minb": 3, "fwd_q": 4, "fwd_nw": 5, "fwd_qj": 6,
-           "fwd_f16_s": 7, "fwd_f16_qg": 8, "vjp_kernel": 9, "vjp_f16_ct": 10, "lds_pad": 11, "fwd_wide_pipe": 12}
+           "fwd_f16_s": 7, "fwd_f16_qg": 8, "vjp_kernel": 9, "vjp_f16_ct": 10, "lds_pad": 11, "fwd_wide_pipe": 12, "tick_fused": 13}
 FWD_AUTO, FWD_K1, FWD_K1M, FWD_K1H = 0, 1, 2, 3
 VJP_AUTO, VJP_K2, VJP_K2H = 0, 1, 2
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "irbfn_nearest_point": (_i, [_fp, _fp, _fp, _fp, _fp, _ip, _i64, _i, _vp]),
     "irbfn_intersect_point": (_i, [_fp, _fp, _fp, _f, _i, _fp, _ip, _fp, _ip, _i64, _i, _vp]),
     "irbfn_cluster_gate": (_i, [_fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp]),
+    "irbfn_net_tick_needs_controls": (_i, [_vp, _i, _i64, _i]),
     "irbfn_net_forward_gamma": (_i, [_vp, _fp, _fp, _fp, _i64, _vp]),
     "irbfn_net_vjp_gamma": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _vp, _i64, _vp]),
     "irbfn_cluster_gate_vjp": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp]),

@@ -38,6 +38,8 @@ UNITS = [
     ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace
     ("rollout.hip", "rollout.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
+    # the fused planning tick: wide K1h forward + K3p roll-out core in one kernel (the roll-out's flags: 50-knot register arrays)
+    ("plan_tick_wide.hip", "plan_tick_wide.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
     ("rollout_vjp.hip", "rollout_vjp.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
     ("train_step.hip", "train_step.o", []),
     ("mlp_head.hip", "mlp_head.o", []),

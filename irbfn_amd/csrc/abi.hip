@@ -70,6 +70,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   net->opt[IRBFN_OPT_FWD_SMALL] = 1;
   net->opt[IRBFN_OPT_FWD_F16_TERMS] = 3;
   net->opt[IRBFN_OPT_FWD_WIDE_PIPE] = 1;
+  net->opt[IRBFN_OPT_TICK_FUSED] = 1;
 
   const size_t tab = (size_t)(nsplit > 0 ? nsplit : 1) * net->max_ranges;
   const size_t nr = (size_t)(n_ranges > 0 ? n_ranges : 1) * (nsplit > 0 ? nsplit : 1);
@@ -272,6 +273,12 @@ int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, cons
   if (rc != IRBFN_OK) return rc;
   return launch_forward_rollout(net, mode, x_dev, nullptr, state0_dev, dp, controls_dev, states_dev, B, T,
                                 as_stream(stream));
+}
+
+int irbfn_net_tick_needs_controls(irbfn_net* net, int mode, int64_t B, int T) {
+  if (!net || rollout_state_dim(mode) < 0) return IRBFN_ERR_BAD_ARG;
+  if (tick_f16_wide_available(net, mode, B, T)) return 0;    // one launch, controls stay in LDS
+  return (prefer_mfma(net) && B > 64) ? 1 : 0;               // forward + split-row roll-out through the caller's buffer
 }
 
 int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, float* out_dev, int64_t B,

@@ -272,6 +272,24 @@ int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, flo
 // IRBFN_OPT_FWD_KERNEL forces another kernel, IRBFN_OPT_FWD_F16_TERMS = 1 selects the reduced-precision
 // single-product variant (reporting only; never reachable without that explicit option).  Geometry: S centre
 // slices x QG query groups of 32 per 8-wave block, S chosen so that the launch has >= 16384 waves.
+// wide outputs (16 < O <= 128): would the automatic dispatch run K1h, and with which block geometry?  Block-shared W
+// stream; SW = centre slices per block so that the grid covers the 256 CUs.  Shared with the fused planning tick
+// (plan_tick_wide.hip), which must reduce the slices in the same order as the plain forward.
+bool f16_wide_geometry(const irbfn_net* net, int64_t B, int* SW_out, int* QG_out) {
+  const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
+  if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return false;
+  if (!net->f16_img || !f16_eligible(net) || net->O <= 16) return false;
+  if (B < opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65)) return false;
+  const long groups = (B + 31) / 32;
+  int SW = 1;
+  while (SW < 4 && (groups * SW + 7) / 8 < 256) SW *= 2;
+  SW = opt_or(net, IRBFN_OPT_FWD_F16_S, SW);
+  if (SW != 1 && SW != 2 && SW != 4) SW = 1;
+  *SW_out = SW;
+  *QG_out = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / SW);
+  return true;
+}
+
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
   if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
@@ -279,12 +297,8 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   if (B < opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65)) return IRBFN_ERR_UNSUPPORTED;
   const long groups = (B + 31) / 32;
   if (net->O > 16) {
-    // wide outputs: block-shared W stream; SW = centre slices per block so that the grid covers the 256 CUs
-    int SW = 1;
-    while (SW < 4 && (groups * SW + 7) / 8 < 256) SW *= 2;
-    SW = opt_or(net, IRBFN_OPT_FWD_F16_S, SW);
-    if (SW != 1 && SW != 2 && SW != 4) SW = 1;
-    const int QGw = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / SW);
+    int SW, QGw;
+    if (!f16_wide_geometry(net, B, &SW, &QGw)) return IRBFN_ERR_UNSUPPORTED;
     return launch_forward_f16(net, x, out, B, SW, QGw, 3, s);
   }
   long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
@@ -337,6 +351,11 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
       mode != IRBFN_ROLLOUT_FRENET_LS)
     return IRBFN_ERR_UNSUPPORTED;
   if (net->O != 2 * T) return IRBFN_ERR_BAD_ARG;
+  {
+    // wide outputs on K1h: the whole tick in one launch where the instance exists (plan_tick_wide.hip)
+    const int rc = launch_tick_f16_wide(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
   if (controls && prefer_mfma(net) && B > 64) {
     // wide outputs: K1m forward into the caller's controls buffer, then the roll-out on split rows
     // (the 2 x B x O x 4 bytes of control traffic are noise next to the B x N x O weight FMAs)

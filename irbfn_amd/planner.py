@@ -31,8 +31,8 @@ def plan_batch(net: WCRBFNet, params: dict, x, state0, dyn_params, mode: int = _
     if tuple(xd.shape) != (B, net.in_features) or sd.reshape(B, -1).shape[1] != s0:
         raise ValueError(f"x must be [B, {net.in_features}] and state0 [B, {s0}]")
     keep, pp = _dyn(dyn_params)
-    # wide nets (O > 16) run the matrix-core forward + split-row roll-out and need the controls buffer
-    need_ctrl = return_controls or net.out_features > 16
+    # wide nets outside the one-launch tick (plan_tick_wide.hip) run forward -> split-row roll-out through a controls buffer
+    need_ctrl = return_controls or lib.irbfn_net_tick_needs_controls(net._handle(torch), mode, B, T) != 0
     ctrl = torch.empty((B, net.out_features), dtype=torch.float32, device=xd.device) if need_ctrl else None
     states = torch.empty((B, T, S), dtype=torch.float32, device=xd.device)
     st = lib.irbfn_net_forward_rollout(net._handle(torch), mode, _ptr(xd), _ptr(sd), pp,

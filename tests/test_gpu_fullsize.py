@@ -85,11 +85,17 @@ def test_cfg4_share_forward_and_tick(gpu):
     net = WCRBFNet.from_config(cfg)
     xt, st = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda()
     ctrl, states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide")                  # ONE launch: forward + roll-out
     u = net.apply(P, xt)
     assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma_wide")
     assert torch.equal(ctrl, u)
     two = dyn.integrate_st_ks_mult(torch.cat([st, u], dim=1), configs.DYN_PARAMS)
     assert torch.equal(states, two)                                                         # fused == two launches
+    net.set_options(tick_fused=0)
+    ctrl2, states2 = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma_wide")
+    net.set_options(tick_fused=1)
+    assert torch.equal(ctrl2, ctrl) and torch.equal(states2, states)
     sub = np.arange(0, B, 8)                                                                # 4096 rows
     ref = co.wcrbf_forward(cfg, P, x[sub], np.float64)
     scale = _terms_scale(cfg, P, x[sub])
@@ -149,3 +155,30 @@ def test_cfg5_forward_full_batch(gpu):
     assert err.max() <= RTOL * np.abs(ref).max() and (err <= RTOL * np.abs(ref) + 3e-6 * scale).all()
     perm = torch.from_numpy(np.random.default_rng(0).permutation(1 << 20)).cuda()          # same batch size = same launch geometry
     assert torch.equal(net.apply(P, xt[perm].contiguous()), out[perm])
+
+
+@pytest.mark.parametrize("B", [32768 + 77, 4099, 262144])
+def test_cfg4_fused_tick_mirror_and_ragged(gpu, B):
+    """The one-launch planning tick (plan_tick_wide.hip) with the planner's mirror flags, on batches that end inside a
+    block / a wave (ragged) and on the whole config-4 batch, for both single-track modes: controls and states equal,
+    bit for bit, to forward -> sign flip -> stand-alone roll-out; states without a controls buffer."""
+    torch = gpu
+    from irbfn_amd.planner import plan_tick
+    cfg, P = configs.model_card(4), configs.synth_params(4)
+    x = configs.synth_queries(4, B=B)
+    st0 = configs.initial_state_from_query(x)
+    mirror = (np.random.default_rng(B).random(B) < 0.5).astype(np.int32)
+    net = WCRBFNet.from_config(cfg)
+    xt, st, mt = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda(), torch.from_numpy(mirror).cuda()
+    T = cfg["out_features"] // 2
+    for mode, fn in ((_lib.ROLLOUT_ST_KS, dyn.integrate_st_ks_mult), (_lib.ROLLOUT_ST_SELECT, dyn.integrate_st_mult)):
+        ctrl, states = plan_tick(net, P, xt, mt, st, configs.DYN_PARAMS, mode=mode)
+        # small batches run 4 centre slices per block (the pipelined kernel's LDS ring does not fit): separate launches
+        assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide" if B > 8192 else "rollout_fwd") or B <= 8192
+        u = net.apply(P, xt).clone()
+        u[:, T:] = torch.where(mt[:, None] != 0, -u[:, T:], u[:, T:])
+        assert torch.equal(ctrl, u)
+        assert torch.equal(states, fn(torch.cat([st, u], dim=1), configs.DYN_PARAMS))
+        _, only_states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=mode, return_controls=False)
+        ref = fn(torch.cat([st, net.apply(P, xt)], dim=1), configs.DYN_PARAMS)
+        assert torch.equal(only_states, ref)
