@@ -340,7 +340,7 @@ def scaling_extras(net, params, x, rank, world, configs, torch):
     wall, _ = timed_region(tick, steps4, 3, world)
     out["cfg4_plan_tick_strong"] = {"traj_per_s": Bt * steps4 / wall, "ms_per_tick": wall / steps4 * 1e3,
                                     "global_batch": Bt, "batch_per_gpu": hi - lo, "scaling": "strong", "steps": steps4,
-                                    "what": "forward O=100 (f16-MFMA wide kernel) + 50-step ST-kinematic roll-out per rank; "
+                                    "what": "forward O=100 (f16-MFMA wide kernel) + 50-step ST-kinematic roll-out per rank, one launch; "
                                             "barrier + synchronize on both sides, max over ranks"}
     del x4, s0
     # --- config 3, WEAK scaling: forward + parameter VJP on each rank's 65536-query shard + ONE all-reduce of the
@@ -364,6 +364,7 @@ def single_gpu_extras(net, params, x, configs, torch):
     """Secondary single-GPU kernel numbers (outside the timed region)."""
     from irbfn_amd import _lib, distributed, dynamics, train
     from irbfn_amd.model import WCRBFNet
+    from irbfn_amd.planner import plan_batch
     out = {}
     B = x.shape[0]
     N, D, O = 4096, 7, 10
@@ -414,7 +415,25 @@ def single_gpu_extras(net, params, x, configs, torch):
         "mfma_f16": {"tflops": pairs4 * 2 * 112 * 3 / t / 1e12, "frac": pairs4 * 2 * 112 * 3 / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
                      "what": "issued f16 MFMA flops: 3 products x 7 column tiles of 16 (O = 100 padded to 112)"},
         "algorithmic_fp32_tflops": pairs4 * (3 * 7 + 2 + 200) / t / 1e12}
-    del x4
+    # the planning tick at the per-GPU share: forward + 50-step roll-out in ONE launch (controls stay in LDS) against
+    # forward -> roll-out as separate launches through a controls buffer, and the forward alone (interleaved repeats)
+    s4 = torch.from_numpy(configs.initial_state_from_query(x4.cpu().numpy())).cuda()
+    tick4 = lambda: plan_batch(net4, p4, x4, s4, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    tf, t1, t2 = [], [], []
+    for _ in range(3):
+        tf.append(_time(lambda: net4(x4), 20, torch))
+        net4.set_options(tick_fused=1)
+        t1.append(_time(tick4, 20, torch))
+        k1 = net4.last_launch()["kernel"]
+        net4.set_options(tick_fused=0)
+        t2.append(_time(tick4, 20, torch))
+        net4.set_options(tick_fused=1)
+    med = lambda v: sorted(v)[len(v) // 2]
+    out["cfg4_plan_tick_per_gpu_share"] = {
+        "batch": 32768, "forward_us": med(tf) * 1e6, "one_launch_us": med(t1) * 1e6, "separate_launches_us": med(t2) * 1e6,
+        "one_launch_minus_forward_us": (med(t1) - med(tf)) * 1e6, "traj_per_s": 32768 / med(t1), "kernel": k1,
+        "what": "forward O=100 + 50-step ST-kinematic roll-out, controls and states written; medians of 3 interleaved rounds x 20"}
+    del x4, s4
     # BASELINE config 5 ("fp32 vs bf16, reduction cast as MFMA GEMM, utilisation reported"): 16384-centre inverse-
     # multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs K1h at float32 accuracy (hi/lo f16 operand pairs), with
     # plain f16 operands and with plain bf16 operands

@@ -188,6 +188,8 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
         }
         t16[t * 8 + j] = f16_arg<BC>(r2, r[RF - 1]);
       }
+      // (the two tiles' distances as v_pk_add_f32 / v_pk_fma_f32 with the centre broadcast by op_sel -- 7 packed instead of
+      // 14 plain instructions per pair of pairs: measured 135.5 vs 131.7-132.3 us at config 2, rejected)
       // one deferred MFMA per centre: (tile, term) = (j & 1, j >> 1); terms: ph*wh -> A1; pls*wh, ph*wls -> A2
       const int t = j & 1, m = j >> 1;
       if (m < TERMS) {

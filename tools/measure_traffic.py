@@ -59,6 +59,8 @@ def main():
         if k.split("<")[0].split("::")[-1] == lib_name.split("<")[0]:
             rec[lib_name] = dict(rec[k], profiler_name=k)
     json.dump(rec, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=2)
+    # gpurun brings back gpurun_out/ only: copy the record from there into profiles/ after the call
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_traffic.json"), "w"), indent=2)
     print(json.dumps(rec, indent=2))
 
 
