@@ -32,13 +32,32 @@ struct VjpArgs {
   float gscale;
 };
 
-// d phi / d(d2) from phi (and d2) for the d2-only bases
+// d phi / d(d2) from phi and d2.  The fast classes need phi only; the generic class covers the bases that depend on
+// d = sqrt(d2) itself (flax_rbf.py:55-111): d phi / d(d2) = phi'(d) * (0.5 / d), evaluated literally so that a query ON a
+// centre (d = 0) gives what jax.grad gives there -- sqrt has no derivative at 0: inf, and inf * 0 = NaN.
 template <int BC>
-__device__ __forceinline__ float dphi_dd2(float phi, float gscale, int basis) {
+__device__ __forceinline__ float dphi_dd2(float phi, float d2, float gscale, int basis) {
   if constexpr (BC == BC_GAUSS) return -gscale * phi;          // exp(-a d2)
   else if constexpr (BC == BC_IQ) return -(phi * phi);         // 1/(1+d2)
   else if constexpr (BC == BC_IMQ) return -0.5f * phi * phi * phi;   // (1+d2)^-1/2
-  else return basis == IRBFN_MULTIQUADRIC ? 0.5f / phi : 1.0f;       // sqrt(1+d2) | d2
+  else {
+    if (basis == IRBFN_MULTIQUADRIC) return 0.5f / phi;        // sqrt(1+d2)
+    if (basis == IRBFN_QUADRATIC) return 1.0f;                 // d2
+    const float d = sqrtf(d2);
+    float dp;                                                  // phi'(d)
+    switch (basis) {
+      case IRBFN_LINEAR: dp = 1.0f; break;                                                    // d
+      case IRBFN_SPLINE: dp = 2.0f * d * logf(d + 1.0f) + d2 / (d + 1.0f); break;             // d^2 log(d + 1)
+      case IRBFN_POISSON_ONE: dp = (2.0f - d) * expf(-d); break;                              // (d - 1) exp(-d)
+      case IRBFN_POISSON_TWO: dp = (2.0f * d - 1.0f - 0.5f * d2) * expf(-d); break;           // ((d - 2) / 2) d exp(-d)
+      case IRBFN_MATERN32: dp = -3.0f * d * expf(-1.7320508075688772f * d); break;            // (1 + sqrt3 d) exp(-sqrt3 d)
+      case IRBFN_MATERN52:                                                                    // (1 + sqrt5 d + 5/3 d^2) exp(-sqrt5 d)
+        dp = -(5.0f / 3.0f) * d * (1.0f + 2.23606797749979f * d) * expf(-2.23606797749979f * d);
+        break;
+      default: dp = 0.0f; break;
+    }
+    return dp * (0.5f / d);
+  }
 }
 
 // Pre-pass: one packed, zero-padded record per query so that the hot loop reads ONE contiguous scalar
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
       gw[OP - 1] = __builtin_fmaf(gphi, g0, gw[OP - 1]);
     }
     const float hbar = hb0 + hb1;
-    const float t = hbar * gam * dphi_dd2<BC>(phi, a.gscale, a.basis);
+    const float t = hbar * gam * dphi_dd2<BC>(phi, d2, a.gscale, a.basis);
     gls = __builtin_fmaf(t, -2.0f * d2, gls);
     const float coef = -2.0f * t * s2;
 #pragma unroll
@@ -554,8 +573,6 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
                float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s,
                const float* gamma_ext) {
   (void)ws_bytes;
-  if (net->bclass == BC_GENERIC && net->basis != IRBFN_MULTIQUADRIC && net->basis != IRBFN_QUADRATIC)
-    return IRBFN_ERR_UNSUPPORTED;   // hand VJP exists for the d^2-only bases
   const long n_c = (long)net->N * net->D, n_l = net->N, n_k = (long)net->K * net->O;
   if (B == 0) {
     IRBFN_HIP_CHECK(hipMemsetAsync(g_centers, 0, n_c * sizeof(float), s));

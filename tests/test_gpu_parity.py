@@ -432,6 +432,35 @@ def test_net_vjp_bases_and_ragged(gpu, basis):
             assert np.abs(a - b).max() <= 5e-5 * np.abs(b).max() + 1e-7, (basis, B, name)
 
 
+@pytest.mark.parametrize("basis", ["linear", "spline", "poisson_one", "poisson_two", "matern32", "matern52"])
+def test_net_vjp_distance_dependent_bases(gpu, basis):
+    """The bases that depend on d = sqrt(d^2) itself (flax_rbf.py:55-111; no reference model card uses them): parameter
+    VJP against torch.autograd of the float64 restatement, two regions and ragged batches; a query ON a centre gives
+    NaN in that centre's gradient, as jax.grad of the reference does (sqrt has no derivative at 0)."""
+    torch = gpu
+    cfg = dict(configs.model_card(1), basis_func=basis)
+    P = configs.synth_params(1)
+    net = WCRBFNet.from_config(cfg)
+    for B in (1, 100, 1500):
+        x = configs.synth_queries(1, B=B)
+        g = configs.synth_cotangent(1, B=B)
+        tp = orc.torch_params(orc.cast_params(P, np.float64), torch.float64, requires_grad=True)
+        out = orc.wcrbfnet_apply(cfg, tp, torch.tensor(x, dtype=torch.float64))
+        (out * torch.tensor(g, dtype=torch.float64)).sum().backward()
+        got = net.vjp(P, x, g)["params"]
+        for grp, name in (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias")):
+            a, b = got[grp][name], tp["params"][grp][name].grad.numpy()
+            assert np.abs(a - b).max() <= 5e-5 * np.abs(b).max() + 1e-7, (basis, B, name, np.abs(a - b).max() / np.abs(b).max())
+    x = configs.synth_queries(1, B=64).copy()
+    c = np.asarray(P["params"]["rbf_list"]["centers"], np.float32)
+    x[7] = c[0, 5]                                                          # query 7 sits on centre 5 of region 0
+    got = net.vjp(P, x, configs.synth_cotangent(1, B=64))["params"]
+    gc = got["rbf_list"]["centers"]
+    assert np.isnan(gc[0, 5]).all()
+    mask = np.ones(gc.shape[:2], bool); mask[0, 5] = False
+    assert np.isfinite(gc[mask]).all() and np.isfinite(got["linear"]["kernel"]).all()
+
+
 def test_net_vjp_cfg3_size_determinism_and_subset(gpu):
     torch = gpu
     cfg = configs.model_card(3)
