@@ -182,3 +182,31 @@ def test_cfg4_fused_tick_mirror_and_ragged(gpu, B):
         _, only_states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=mode, return_controls=False)
         ref = fn(torch.cat([st, net.apply(P, xt)], dim=1), configs.DYN_PARAMS)
         assert torch.equal(only_states, ref)
+
+
+@pytest.mark.parametrize("basis,T", [("inverse_quadratic", 50), ("inverse_multiquadric", 50), ("gaussian", 49), ("gaussian_wide", 53)])
+def test_cfg4_fused_tick_other_instances(gpu, basis, T):
+    """The other instances of the one-launch tick (inverse-quadratic / inverse-multiquadric basis, T = 49: O = 98 in the
+    same seven column tiles) against forward -> stand-alone roll-out, bit for bit; T = 53 (O = 106) has no instance
+    (the lanes hold 50 control knots) and must take the separate launches with the same results."""
+    torch = gpu
+    cfg = dict(configs.model_card(4), basis_func=basis, out_features=2 * T)
+    P = configs.synth_params(4)
+    rng = np.random.default_rng(T)
+    P["params"]["linear"] = {"kernel": rng.normal(0.0, 0.05, size=(cfg["num_kernels"], 2 * T)).astype(np.float32),
+                             "bias": rng.normal(0.0, 0.1, size=(2 * T,)).astype(np.float32)}
+    B = 33000
+    x = configs.synth_queries(4, B=B)
+    st0 = configs.initial_state_from_query(x)
+    net = WCRBFNet.from_config(cfg)
+    xt, st = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda()
+    ctrl, states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    fused = net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide")
+    assert fused == (T <= 50)
+    u = net.apply(P, xt)
+    assert torch.equal(ctrl, u)
+    assert tuple(states.shape) == (B, T, 7)
+    assert torch.equal(states, dyn.integrate_st_ks_mult(torch.cat([st, u], dim=1), configs.DYN_PARAMS))
+    ref = co.wcrbf_forward(cfg, P, x[:512], np.float64)
+    err = np.abs(u.cpu().numpy()[:512].astype(np.float64) - ref)
+    assert err.max() <= RTOL * np.abs(ref).max()
