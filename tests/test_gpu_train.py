@@ -291,3 +291,38 @@ def test_train_step_fullint_withcluster(gpu):
             nxt["params"].setdefault(g_, {})[n_] = p_ref[off:off + cnt].reshape(shp)
             off += cnt
         cur = nxt
+
+
+def test_train_step_two_ranks_unequal_shards(gpu, tmp_path):
+    """The multi-rank branch of the train step (one all-reduce of [B_local * g, B_local * loss, B_local]): two ranks share
+    cuda:0 over gloo with shards of 151 and 150 rows; parameters, gradient and loss after two steps equal the
+    single-process steps on the whole 301-row batch (the global-batch mean, whatever the shard sizes)."""
+    import os
+    import subprocess
+    import sys
+    cfg = configs.model_card(3)
+    P = configs.synth_params(3)
+    B = 301
+    x = configs.synth_queries(3, B=B)
+    y = np.random.default_rng(8).normal(size=(B, cfg["out_features"])).astype(np.float32)
+    p = P["params"]
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, x=x, y=y, centers=p["rbf_list"]["centers"], log_sigs=p["rbf_list"]["log_sigs"],
+             kernel=p["linear"]["kernel"], bias=p["linear"]["bias"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547", os.path.join(root, "tests", "_train_two_ranks.py"), inp, out],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = np.load(out)
+    assert tuple(two["shard"]) == (0, 151)
+    net = WCRBFNet.from_config(cfg)
+    state = train.TrainState.create(net, P, lr=1e-3, max_grad_norm=1.0)
+    losses = []
+    for _ in range(2):
+        state, loss = train.train_step_oneint(state, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), DP)
+        losses.append(float(loss))
+    g1, f1 = state.g.cpu().numpy(), state.flat.cpu().numpy()
+    assert np.abs(two["losses"] - np.array(losses)).max() <= 2e-6 * np.abs(losses).max(), (two["losses"], losses)
+    assert np.abs(two["g"] - g1).max() <= 2e-5 * np.abs(g1).max()
+    assert np.abs(two["flat"] - f1).max() <= 2e-6 + 1e-6 * np.abs(f1).max()
