@@ -386,6 +386,20 @@ def single_gpu_extras(net, params, x, configs, torch):
     out["cfg3_train_step_oneint"] = {"evals_per_s": B / t, "ms": t * 1e3, "batch": B,
                                      "what": "fwd + loss seeds + param VJP + clip_by_global_norm + adam, no host sync"}
     net.bind(params)
+    # the planning tick of a narrow net (O = 10 = 2 x 5 knots, what the reference's trained planners are): forward +
+    # sign flip + 5-step kinematic roll-out in ONE launch of the matrix-core kernel, beside the forward alone
+    s2 = torch.from_numpy(configs.initial_state_from_query(x.cpu().numpy())).cuda()
+    tick2 = lambda: plan_batch(net, params, x, s2, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    tfw, ttk = [], []
+    for _ in range(3):
+        tfw.append(_time(lambda: net(x), 30, torch))
+        ttk.append(_time(tick2, 30, torch))
+    k2 = net.last_launch()["kernel"]
+    out["cfg2_plan_tick_T5"] = {"batch": B, "forward_us": sorted(tfw)[1] * 1e6, "one_launch_us": sorted(ttk)[1] * 1e6,
+                                "traj_per_s": B / sorted(ttk)[1], "kernel": k2,
+                                "what": "config-2 net (O = 10): forward + 5-step ST-kinematic roll-out, controls and states written; "
+                                        "medians of 3 interleaved rounds x 30"}
+    del s2
     # roll-out alone (the HBM-bound kernel): T = 50, kinematic single track; per-GPU share and whole cfg-4 batch
     T = 50
     for key, Bt, reps in (("rollout_st_ks_T50_per_gpu_share", 32768, 50), ("rollout_st_ks_T50_whole_cfg4_batch", 262144, 20)):

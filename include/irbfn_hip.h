@@ -117,8 +117,9 @@ typedef enum irbfn_option {
   IRBFN_OPT_VJP_F16_CT = 10,   /* K2h: 16-centre tiles per wave (2 default, 4) */
   IRBFN_OPT_LDS_PAD = 11,      /* diagnosis: extra dynamic LDS bytes per workgroup of K1h / K2h (lowers occupancy) */
   IRBFN_OPT_FWD_WIDE_PIPE = 12,/* K1h, 16 < O <= 128: 1 (default) pipelined kernel (deferred MFMAs, LDS-DMA ring of three), 0: two-buffer kernel */
-  IRBFN_OPT_TICK_FUSED = 13,   /* planning tick with wide outputs: 1 (default) one launch where the instance exists (d = 7, O = 2T in
-                                  (96, 112], single-track modes), 0: forward + sign flip + roll-out launches */
+  IRBFN_OPT_TICK_FUSED = 13,   /* planning tick on the matrix-core kernels: 1 (default) one launch where the instance exists (wide: d = 7,
+                                  O = 2T in (96, 112], single-track modes; narrow: O = 2T <= 16, d = 7 single-track / inline bicycle,
+                                  d = 8 Frenet), 0: forward + sign flip + roll-out launches */
   IRBFN_OPT_COUNT = 14
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
@@ -183,9 +184,9 @@ int irbfn_rollout_vjp(int mode, const float* x0u_dev, const float* dyn_params_ho
 int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, const float* state0_dev,
                               const float* dyn_params_host, float* controls_dev, float* states_dev,
                               int64_t B, int T, void* stream);
-/* 1 if irbfn_net_forward_rollout / irbfn_plan_tick with a states output need a controls buffer for this net, mode,
- * batch and horizon (wide outputs outside the one-launch tick run forward -> roll-out through it), 0 if controls_dev
- * may be NULL, < 0 on a bad argument. */
+/* 1 if irbfn_net_forward_rollout / irbfn_plan_tick with a states output run forward -> roll-out through the caller's
+ * controls buffer for this net, mode, batch and horizon (wide outputs need it, narrow ones on the matrix-core kernel are
+ * faster with it), 0 if the tick is one launch and controls_dev may be NULL, < 0 on a bad argument. */
 int irbfn_net_tick_needs_controls(irbfn_net* net, int mode, int64_t B, int T);
 
 /* ---------------------------------------------------------------------------------------------

@@ -277,8 +277,8 @@ int irbfn_net_forward_rollout(irbfn_net* net, int mode, const float* x_dev, cons
 
 int irbfn_net_tick_needs_controls(irbfn_net* net, int mode, int64_t B, int T) {
   if (!net || rollout_state_dim(mode) < 0) return IRBFN_ERR_BAD_ARG;
-  if (tick_f16_wide_available(net, mode, B, T)) return 0;    // one launch, controls stay in LDS
-  return (prefer_mfma(net) && B > 64) ? 1 : 0;               // forward + split-row roll-out through the caller's buffer
+  if (tick_f16_wide_available(net, mode, B, T) || tick_f16_narrow_available(net, mode, B, T)) return 0;    // one launch, controls stay in LDS
+  return tick_through_controls(net, B) ? 1 : 0;              // forward + split-row roll-out through the caller's buffer
 }
 
 int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, float* out_dev, int64_t B,

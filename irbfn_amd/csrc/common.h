@@ -105,6 +105,11 @@ bool f16_eligible(const irbfn_net* net);
 size_t f16_image_bytes(const irbfn_net* net);
 int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s);
+bool tick_through_controls(const irbfn_net* net, int64_t B);
+bool f16_narrow_geometry(const irbfn_net* net, int64_t B, int* S, int* QG);
+bool tick_f16_narrow_available(const irbfn_net* net, int mode, int64_t B, int T);
+int launch_tick_f16_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0,
+                           const DynParams& dp, float* controls, float* states, int64_t B, int T, hipStream_t s);
 bool f16_wide_geometry(const irbfn_net* net, int64_t B, int* SW, int* QG);
 void f16_wide_normalize(const irbfn_net* net, int* SW, int* QG, bool* pipe);
 bool tick_f16_wide_available(const irbfn_net* net, int mode, int64_t B, int T);

@@ -290,6 +290,28 @@ bool f16_wide_geometry(const irbfn_net* net, int64_t B, int* SW_out, int* QG_out
   return true;
 }
 
+// narrow outputs (O <= 16): would the automatic dispatch run K1h, and with which block geometry?  S centre slices x QG
+// query groups of 32 per 8-wave block, S chosen so that the launch has >= 16384 waves.  Shared with the one-launch tick.
+bool f16_narrow_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_out) {
+  const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
+  if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return false;
+  if (!net->f16_img || !f16_eligible(net) || net->O > 16) return false;
+  if (B < opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65)) return false;
+  const long groups = (B + 31) / 32;
+  long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
+  int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
+  S = pow2_floor(S);
+  if (S < want && S < 8) S *= 2;
+  const int nchunks = (net->N + 31) / 32;
+  while (S > 1 && nchunks / S < 2) S /= 2;
+  S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
+  if (S > 8 || S > nchunks) S = 1;
+  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
+  if (S * QG > 8) QG = 1;
+  *S_out = S; *QG_out = QG;
+  return true;
+}
+
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
   if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
@@ -301,16 +323,8 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
     if (!f16_wide_geometry(net, B, &SW, &QGw)) return IRBFN_ERR_UNSUPPORTED;
     return launch_forward_f16(net, x, out, B, SW, QGw, 3, s);
   }
-  long want = (16384 + groups - 1) / groups;           // measured at cfg-2: S = 8 (16384 waves) 131 us, S = 4 134 us
-  int S = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
-  S = pow2_floor(S);
-  if (S < want && S < 8) S *= 2;
-  const int nchunks = (net->N + 31) / 32;
-  while (S > 1 && nchunks / S < 2) S /= 2;
-  S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
-  if (S > 8 || S > nchunks) S = 1;
-  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
-  if (S * QG > 8) QG = 1;
+  int S, QG;
+  if (!f16_narrow_geometry(net, B, &S, &QG)) return IRBFN_ERR_UNSUPPORTED;
   const int ot = net->opt[IRBFN_OPT_FWD_F16_TERMS];
   const int terms = (ot == 1 || ot == 2) ? ot : 3;           // 1: plain f16, 2: plain bf16 (both reporting only), 3: pairs
   return launch_forward_f16(net, x, out, B, S, QG, terms, s);
@@ -337,6 +351,12 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
   return run_forward(net, a, false, s);
 }
 
+// the tick runs forward -> roll-out through a controls buffer (when the caller provides one)
+bool tick_through_controls(const irbfn_net* net, int64_t B) {
+  int S, QG;
+  return B > 64 && (prefer_mfma(net) || f16_narrow_geometry(net, B, &S, &QG));
+}
+
 int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0,
                            const DynParams& dp, float* controls, float* states, int64_t B, int T,
                            hipStream_t s) {
@@ -352,13 +372,16 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
     return IRBFN_ERR_UNSUPPORTED;
   if (net->O != 2 * T) return IRBFN_ERR_BAD_ARG;
   {
-    // wide outputs on K1h: the whole tick in one launch where the instance exists (plan_tick_wide.hip)
-    const int rc = launch_tick_f16_wide(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
+    // K1h nets: the whole tick in one launch where the instance exists (wide: plan_tick_wide.hip; narrow: rbf_tick_f16mfma)
+    int rc = launch_tick_f16_wide(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+    rc = launch_tick_f16_narrow(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   }
-  if (controls && prefer_mfma(net) && B > 64) {
-    // wide outputs: K1m forward into the caller's controls buffer, then the roll-out on split rows
-    // (the 2 x B x O x 4 bytes of control traffic are noise next to the B x N x O weight FMAs)
+  if (controls && tick_through_controls(net, B)) {
+    // wide outputs, and narrow ones on K1h without a one-launch instance: forward into the caller's controls buffer,
+    // then the roll-out on split rows (K1h forward + K3 beat K1 with the roll-out in its epilogue: 134 + 17 vs 173 us
+    // at config 2's size; the 2 x B x O x 4 bytes of control traffic are noise next to the B x N pair work)
     int rc = launch_forward(net, x, controls, B, s);
     if (rc == IRBFN_OK && mirror) rc = launch_unmirror(controls, mirror, B, net->O, T, s);
     if (rc != IRBFN_OK) return rc;

@@ -109,10 +109,14 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__
 
 // TERMS: 3 = (hi, lo) f16 pairs (the product path); 1 = plain f16 operands; BF (with TERMS = 1) = plain bf16 operands --
 // the two reduced-precision variants BASELINE config 5 asks to report, reachable only through an explicit option.
-template <int DC, int BC, int TERMS, bool BF = false>
-__global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(const F16Args a) {
+// ROLL (rbf_tick_f16mfma, the planning tick of the narrow nets: irbfn_planner.py:203-212): the slice-0 wave of a query
+// group keeps its 32 rows of controls in LDS and integrates the trajectories itself -- see the epilogue.
+constexpr int kTickNarrowT = 8;       // horizons of the narrow tick: O = 2T <= 16
+constexpr int kTickNarrowCP = 17;     // controls tile pitch (floats), odd
+constexpr int kTickNarrowSP = 65;     // states staging pitch: T * S <= 64 floats per row, odd
+template <int DC, int BC, int TERMS, bool BF, bool ROLL>
+__device__ __forceinline__ void narrow_body(const F16Args& a, const F16Roll& rl, int mode, unsigned char* lds) {
   static_assert(!BF || TERMS == 1, "bf16 operands: single product");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RF = f16_rf(DC);
   constexpr int RECB = kF16Chunk * RF * 4;                   // record bytes per chunk
   constexpr int CB = f16_chunk_bytes(DC);
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
   __syncthreads();                                           // every wave is done with its ring
   float* red = reinterpret_cast<float*>(lds);                // [QG][S][2][4][64]
   float* gl = red + (size_t)a.QG * S * 2 * 4 * 64;           // [QG][32]
+  [[maybe_unused]] float* ctile = gl + a.QG * 32;            // ROLL: [QG * 32][kTickNarrowCP] controls, then the states staging tiles
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -268,9 +273,93 @@ __global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(cons
         for (int s2 = 0; s2 < S; ++s2) v += red[(((qg * S + s2) * 2 + t) * 4 + r) * 64 + lane];
         const int row = t * 16 + 4 * g + r;                  // D layout: row = 4 (lane >> 4) + reg
         const long q = q0 + row;
-        if (q < a.B) a.out[q * a.O + n] = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);   // model.py:193-196
+        float y = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);                             // model.py:193-196
+        if constexpr (ROLL) {
+          if (rl.mirror != nullptr && n >= rl.T && q < a.B && rl.mirror[q] != 0) y = -y;     // irbfn_planner.py:203-204
+          ctile[(qg * 32 + row) * kTickNarrowCP + n] = y;
+        }
+        if (q < a.B && a.out != nullptr) a.out[q * a.O + n] = y;
       }
   }
+  if constexpr (ROLL) {
+    // ---- the wave that produced the 32 rows rolls them out: lane l < 32 integrates row l (the step functions of the
+    // stand-alone kernels, rollout_step.h: same bits), the T x S states of the wave's rows -- one contiguous block of
+    // HBM -- are staged row by row in LDS and leave as coalesced dwords
+    if (slice != 0) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int T = rl.T;
+    const long left = a.B - q0;
+    const int nvalid = left < 32 ? (left > 0 ? (int)left : 0) : 32;
+    const int S = (mode == IRBFN_ROLLOUT_FULLINT) ? 5 : (mode == IRBFN_ROLLOUT_FRENET_LS ? 8 : 7);
+    float u[2 * kTickNarrowT];
+    if (lane < 32) {
+      const float* ur = ctile + (qg * 32 + lane) * kTickNarrowCP;
+#pragma unroll
+      for (int i = 0; i < 2 * kTickNarrowT; ++i) u[i] = ur[i];                               // slots >= O hold stale LDS: unused
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                                                         // the controls tile becomes the staging tile
+    float* stage = ctile + (size_t)a.QG * 32 * kTickNarrowCP + (size_t)qg * 32 * kTickNarrowSP;
+    if (lane < nvalid) {
+      const long b = q0 + lane;
+      float* o = stage + lane * kTickNarrowSP;
+      auto ctl = [&](int i) {                                                                // u[i], i wave-uniform: static register index
+        float v = u[0];
+#pragma unroll
+        for (int k = 1; k < 2 * kTickNarrowT; ++k) v = (i == k) ? u[k] : v;
+        return v;
+      };
+      if (mode == IRBFN_ROLLOUT_ST_SELECT || mode == IRBFN_ROLLOUT_ST_KS) {
+        float st[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st[i] = rl.state0[b * 7 + i];
+        for (int t = 0; t < T; ++t) {
+          if (mode == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(st, ctl(t), ctl(T + t), rl.dp);
+          else st_step<false>(st, ctl(t), ctl(T + t), rl.dp);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) o[t * 7 + i] = st[i];
+        }
+      } else if (mode == IRBFN_ROLLOUT_FRENET_LS) {
+        float st[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = rl.state0[b * 8 + i];
+        for (int t = 0; t < T; ++t) {
+          frenet_step(st, ctl(t), ctl(T + t), rl.dp);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[t * 8 + i] = st[i];
+        }
+      } else {
+        float st[5] = {0.0f, 0.0f, 0.0f, clipf(rl.state0[b], 0.0f, 7.0f), 0.0f};             // train_nmpc.py:319
+        for (int t = 0; t < T; ++t) {
+          fullint_step(st, ctl(t), ctl(T + t));
+#pragma unroll
+          for (int i = 0; i < 5; ++i) o[t * 5 + i] = st[i];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int rowf = T * S;                                                                  // floats per trajectory (<= 64)
+    float* gout = rl.states + q0 * (long)rowf;
+    for (int idx = lane; idx < nvalid * rowf; idx += 64) {
+      const int r = idx / rowf, c = idx - r * rowf;
+      gout[idx] = stage[r * kTickNarrowSP + c];
+    }
+  }
+}
+
+template <int DC, int BC, int TERMS, bool BF = false>
+__global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_fwd_f16mfma(const F16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  narrow_body<DC, BC, TERMS, BF, false>(a, F16Roll{}, -1, lds);
+}
+
+// the planning tick of a narrow net in one launch (forward + sign flip + roll-out)
+template <int DC, int BC>
+__global__ __launch_bounds__(512, IRBFN_K1H_MIN_WAVES) void rbf_tick_f16mfma(const F16Args a, const F16Roll rl, const int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  narrow_body<DC, BC, 3, false, true>(a, rl, mode, lds);
 }
 
 // ---- wide outputs (16 < O <= 128): NT = ceil(O/16) column tiles ----------------------------------------------
@@ -573,6 +662,65 @@ template <int DC>
 static int launch_f16_dc(const F16Args& a, int terms, int bc, int grid, int block, size_t lds, hipStream_t s) {
   if (terms == 2) return launch_f16_bc<DC, 1, true>(a, bc, grid, block, lds, s);       // plain bf16 operands
   return terms == 1 ? launch_f16_bc<DC, 1>(a, bc, grid, block, lds, s) : launch_f16_bc<DC, 3>(a, bc, grid, block, lds, s);
+}
+
+template <int DC>
+static int launch_tick_narrow_bc(const F16Args& a, const F16Roll& rl, int mode, int bc, int grid, int block, size_t lds, hipStream_t s) {
+  switch (bc) {
+    case BC_GAUSS: hipLaunchKernelGGL((rbf_tick_f16mfma<DC, BC_GAUSS>), dim3(grid), dim3(block), lds, s, a, rl, mode); break;
+    case BC_IQ: hipLaunchKernelGGL((rbf_tick_f16mfma<DC, BC_IQ>), dim3(grid), dim3(block), lds, s, a, rl, mode); break;
+    case BC_IMQ: hipLaunchKernelGGL((rbf_tick_f16mfma<DC, BC_IMQ>), dim3(grid), dim3(block), lds, s, a, rl, mode); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// does the one-launch tick of a narrow net exist (and is it enabled) for this net / mode / batch / horizon?
+static bool tick_narrow_plan(const irbfn_net* net, int mode, int64_t B, int T, int* S_out, int* QG_out, size_t* lds_out) {
+  if (net->opt[IRBFN_OPT_TICK_FUSED] == 0 || net->O > 16 || net->O != 2 * T || T > kTickNarrowT) return false;
+  const bool st = mode == IRBFN_ROLLOUT_ST_SELECT || mode == IRBFN_ROLLOUT_ST_KS || mode == IRBFN_ROLLOUT_FULLINT;
+  if (!((st && net->DC == 7) || (mode == IRBFN_ROLLOUT_FRENET_LS && net->DC == 8))) return false;
+  if (net->opt[IRBFN_OPT_FWD_F16_TERMS] != 3 && net->opt[IRBFN_OPT_FWD_F16_TERMS] != 0) return false;
+  int S, QG;
+  if (!f16_narrow_geometry(net, B, &S, &QG)) return false;   // the forward would not run K1h
+  const int waves = S * QG;
+  const size_t ring = (size_t)waves * 2 * (kF16Chunk * f16_rf(net->DC) * 4 + 2 * kF16WBytes);
+  const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32 + (size_t)QG * 32 * (kTickNarrowCP + kTickNarrowSP)) * sizeof(float);
+  const size_t lds = ring > red ? ring : red;
+  if (lds > 64 * 1024) return false;
+  *S_out = S; *QG_out = QG; *lds_out = lds;
+  return true;
+}
+
+bool tick_f16_narrow_available(const irbfn_net* net, int mode, int64_t B, int T) {
+  int S, QG;
+  size_t lds;
+  return tick_narrow_plan(net, mode, B, T, &S, &QG, &lds);
+}
+
+// IRBFN_ERR_UNSUPPORTED: no instance -> the caller takes another path
+int launch_tick_f16_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0,
+                           const DynParams& dp, float* controls, float* states, int64_t B, int T, hipStream_t s) {
+  int S, QG;
+  size_t lds;
+  if (!tick_narrow_plan(net, mode, B, T, &S, &QG, &lds)) return IRBFN_ERR_UNSUPPORTED;
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  F16Args a;
+  a.x = x; a.img = net->f16_img; a.oscale = net->f16_oscale; a.bias = net->bias; a.out = controls; a.gate = net->gate();
+  a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.nchunks = nchunks; a.S = S; a.QG = QG;
+  F16Roll rl;
+  rl.state0 = state0; rl.states = states; rl.mirror = mirror; rl.T = T; rl.wlds = 0; rl.dp = dp;
+  const long groups = (B + 31) / 32;
+  const int grid = (int)((groups + QG - 1) / QG);
+  const int rc = net->DC == 7 ? launch_tick_narrow_bc<7>(a, rl, mode, net->bclass, grid, S * QG * 64, lds, s)
+                              : launch_tick_narrow_bc<8>(a, rl, mode, net->bclass, grid, S * QG * 64, lds, s);
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_tick_f16mfma<D=%d,BC=%d,MODE=%d,S=%d,QG=%d>", net->DC, net->bclass, mode, S, QG);
+    net->last_grid = grid;
+    net->last_block = S * QG * 64;
+  }
+  return rc;
 }
 
 // S = centre slices per query group, QG = query groups (of 32) per block; S * QG <= 8 waves

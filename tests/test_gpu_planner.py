@@ -171,3 +171,60 @@ def test_waypoint_geometry_matches_the_restatement(gpu):
                 nfound += 1
                 assert found[b] == 1 and fi[b] == ri and abs(ft[b] - rt) <= 2e-4 and np.abs(fp[b] - rp).max() <= 1e-3
         assert (nfound > 400) if radius < 10 else (nfound == 0)      # a 60 m look-ahead circle misses a 23 m track
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode_name,D,T,B", [("st_ks", 7, 5, 4099), ("st_select", 7, 5, 70000), ("st_ks", 7, 1, 1000),
+                                             ("st_ks", 7, 8, 333), ("fullint", 7, 5, 2500), ("frenet", 8, 5, 4099)])
+def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B):
+    """The planning tick of the narrow nets on the matrix-core kernel (`rbf_tick_f16mfma`: forward + sign flip + roll-out
+    by the wave that produced the rows): controls and states equal, bit for bit, the forward followed by the stand-alone
+    roll-out kernel -- all four models, T = 1 / 5 / 8, ragged batches, mirror flags, with and without a controls buffer;
+    the forward itself against the float64 restatement."""
+    import torch
+    from irbfn_amd import _lib, configs, dynamics as dyn
+    from irbfn_amd.model import WCRBFNet
+    from irbfn_amd.planner import plan_batch, plan_tick
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(B + T)
+    K, O = 512, 2 * T
+    lo, hi = [-1.0] * D, [1.0] * D
+    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": "gaussian", "num_regions": 1,
+           "lower_bounds": [[v] for v in lo], "upper_bounds": [[v] for v in hi], "dimension_ranges": [[0] * D],
+           "activation_idx": list(range(D)), "delta": [5.0] * D}
+    P = {"params": {"rbf_list": {"centers": rng.uniform(-1.2, 1.2, size=(1, K, D)).astype(np.float32),
+                                 "log_sigs": rng.uniform(-0.5, 0.3, size=(1, K)).astype(np.float32)},
+                    "linear": {"kernel": (rng.normal(size=(K, O)) * 0.2).astype(np.float32),
+                               "bias": (rng.normal(size=(O,)) * 0.1).astype(np.float32)}}}
+    x = rng.uniform(-1, 1, size=(B, D)).astype(np.float32)
+    mode = {"st_ks": _lib.ROLLOUT_ST_KS, "st_select": _lib.ROLLOUT_ST_SELECT, "fullint": _lib.ROLLOUT_FULLINT,
+            "frenet": _lib.ROLLOUT_FRENET_LS}[mode_name]
+    if mode_name == "fullint":
+        st0 = rng.uniform(0.5, 6.0, size=(B, 1)).astype(np.float32)
+    elif mode_name == "frenet":
+        st0 = np.hstack([rng.normal(size=(B, 1)) * 0.2, rng.normal(size=(B, 1)) * 0.2, rng.normal(size=(B, 1)) * 0.1,
+                         rng.uniform(1, 6, size=(B, 1)), rng.normal(size=(B, 3)) * 0.1, rng.normal(size=(B, 1)) * 0.05]).astype(np.float32)
+    else:
+        st0 = np.hstack([rng.normal(size=(B, 3)) * 0.3, rng.uniform(0.5, 7.0, size=(B, 1)), rng.normal(size=(B, 3)) * 0.2]).astype(np.float32)
+    mirror = (rng.random(B) < 0.5).astype(np.int32)
+    net = WCRBFNet.from_config(cfg)
+    xt, st, mt = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda(), torch.from_numpy(mirror).cuda()
+    ctrl, states = plan_tick(net, P, xt, mt, st, configs.DYN_PARAMS, mode=mode)
+    assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma<")
+    u = net.apply(P, xt).clone()
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<")
+    ref = co.wcrbf_forward(cfg, P, x, np.float64)
+    assert np.abs(u.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    u[:, T:] = torch.where(mt[:, None] != 0, -u[:, T:], u[:, T:])
+    assert torch.equal(ctrl, u)
+    x0u = torch.cat([st, u], dim=1)
+    two = dyn.rollout_forward(mode, x0u, configs.DYN_PARAMS if mode_name != "fullint" else None, T)
+    assert tuple(states.shape) == tuple(two.shape) and torch.equal(states, two)
+    _, s2 = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=mode, return_controls=False)          # no controls buffer
+    assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma<")
+    plain = dyn.rollout_forward(mode, torch.cat([st, net.apply(P, xt)], dim=1), configs.DYN_PARAMS if mode_name != "fullint" else None, T)
+    assert torch.equal(s2, plain)
+    net.set_options(tick_fused=0)                                                                    # forward -> roll-out launches
+    c3, s3 = plan_tick(net, P, xt, mt, st, configs.DYN_PARAMS, mode=mode)
+    assert not net.last_launch()["kernel"].startswith("rbf_tick")
+    assert torch.equal(c3, ctrl) and torch.equal(s3, states)
