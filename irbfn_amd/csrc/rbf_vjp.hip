@@ -169,11 +169,18 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
       gw[OP - 1] = __builtin_fmaf(gphi, g0, gw[OP - 1]);
     }
     const float hbar = hb0 + hb1;
+    // the centre's own factor -2 / sigma^2 multiplies the finished sums, not every pair:
+    // d log_sig += t * (-2 d2) = (-2 s2) * t * r2,   d centre += (-2 t s2) * diff = (-2 s2) * t * diff
     const float t = hbar * gam * dphi_dd2<BC>(phi, d2, a.gscale, a.basis);
-    gls = __builtin_fmaf(t, -2.0f * d2, gls);
-    const float coef = -2.0f * t * s2;
+    gls = __builtin_fmaf(t, r2, gls);
 #pragma unroll
-    for (int j = 0; j < D; ++j) gc[j] = __builtin_fmaf(coef, diff[j], gc[j]);
+    for (int j = 0; j < D; ++j) gc[j] = __builtin_fmaf(t, diff[j], gc[j]);
+  }
+  {
+    const float m2s = -2.0f * s2;
+    gls *= m2s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) gc[j] *= m2s;
   }
 
   // combine the 4 waves through LDS (fixed order), write the slab row of this block

@@ -268,11 +268,11 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
             float pw = phi;
             if constexpr (BC == BC_IQ) pw = phi * phi;
             if constexpr (BC == BC_IMQ) pw = phi * phi * phi;
+            // the centre's own factor -2 / sigma^2 (s2m2) multiplies the finished sums, not every pair
             const float tt = hb[ct][r] * kq[u] * pw;
-            gls[ct] = __builtin_fmaf(tt, r2[u][ct] * s2m2[ct], gls[ct]);      // tt * (-2 d2)
-            const float coef = tt * s2m2[ct];                                  // -2 tt / sigma^2
+            gls[ct] = __builtin_fmaf(tt, r2[u][ct], gls[ct]);                  // x s2m2 -> tt * (-2 d2)
 #pragma unroll
-            for (int j = 0; j < DC; ++j) gc[ct][j] = __builtin_fmaf(coef, diff[u][ct][j], gc[ct][j]);
+            for (int j = 0; j < DC; ++j) gc[ct][j] = __builtin_fmaf(tt, diff[u][ct][j], gc[ct][j]);   // x s2m2 -> -2 tt / sigma^2
           }
       }
       // dW of the half: rows = outputs, cols = centres, k = the lane's 4 queries
@@ -302,12 +302,12 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
       float v = gc[ct][j];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      gc[ct][j] = v;
+      gc[ct][j] = v * s2m2[ct];
     }
     float v = gls[ct];
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    gls[ct] = v;
+    gls[ct] = v * s2m2[ct];
   }
   // ---- 4 waves (query slices) summed in fixed order through LDS, slab row written (format of rbf_vjp_kernel)
   __syncthreads();
