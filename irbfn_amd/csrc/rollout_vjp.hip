@@ -262,8 +262,11 @@ struct RollVjp2Args {
 };
 
 constexpr int kVjpWaves = 2, kVjpRPP = 16;
-constexpr int vjp_group(int TCH) { return TCH >= 10 ? 10 : TCH; }
-constexpr int vjp_pitch(int S, int G) { return (G * S + 6) | 1; }       // aligned superset of G*S floats, odd
+constexpr int vjp_group(int TCH) { return TCH >= 10 ? 5 : TCH; }
+// a row's seed chunk (G*S floats + up to 3 in front for the 16-byte alignment) as NPC 16-byte pieces; the tile is filled by
+// LDS-DMA, so a row is NPC * 4 floats and NPC is odd (rows of an even number of pieces would fall on 4 or 8 banks)
+constexpr int vjp_pieces(int S, int G) { return ((G * S + 6) / 4) | 1; }
+constexpr int vjp_pitch(int S, int G) { return 4 * vjp_pieces(S, G); }
 
 template <int MODE>
 __device__ __forceinline__ void vjp_fwd_step(float* s, float a_in, float sv_in, const DynParams& dp) {
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(con
   constexpr int S = VjpTraits<MODE>::S, S0 = VjpTraits<MODE>::S0, NP = VjpTraits<MODE>::NP;
   constexpr int G = vjp_group(TCH), NG = TCH / G;
   constexpr int PITCH = vjp_pitch(S, G);
-  constexpr int NPC = (G * S + 6) / 4;           // 16-byte pieces of a row's aligned seed chunk
+  constexpr int NPC = vjp_pieces(S, G);          // 16-byte pieces of a row's aligned seed chunk
   constexpr int RPP = kVjpRPP;
   static_assert(TCH % G == 0, "whole groups");
   const int lane = threadIdx.x & (kWave - 1);
@@ -377,39 +380,45 @@ __global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(con
   float lam[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) lam[i] = 0.0f;
+  // The seeds of a group are requested ONE GROUP AHEAD by LDS-DMA (global_load_lds_dwordx4, gathered 16-byte pieces: no
+  // staging VGPRs) into the other of two row tiles: fetched at the top of the group that needs them they cost half the
+  // kernel (157 us without the seeds against 315 us with them, at B = 262144, T = 50) -- the latency of a dependent
+  // global -> register -> LDS round trip per group with two waves per SIMD to hide it.
+  float* tile2 = tile + kWave * PITCH;
+  auto request = [&](int gq, float* dst) {       // seeds of group gq -> dst (asynchronous; retired by vmcnt)
+    const int tq = gq * G;
+    const int nq = (T - tq) < G ? (T - tq) : G;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int idx = j * kWave + lane;
+      const int r = idx / NPC, part = idx - r * NPC;
+      const int C = (g4 + (int)((r * rs + (long)tq * S) & 3)) & 3;
+      const float* src = gs_tile + r * rs + (long)tq * S - C + 4 * part;        // 16-byte aligned, inside the tile
+      if (4 * part < C + nq * S)
+        __builtin_amdgcn_global_load_lds((vgptr_t)src, (vlptr_t)(dst + j * 256), 16, 0, 0);
+    }
+  };
+  const int g_last = (T - 1) / G;                // the last group with steps
+  int cbuf = 0;
+  if (dma) request(g_last, tile);
 #pragma unroll 1
   for (int gI = NG - 1; gI >= 0; --gI) {
     const int t0 = gI * G;
     if (t0 < T) {                                // wave-uniform
       const int n = (T - t0) < G ? (T - t0) : G;
-      // seeds of steps [t0, t0 + n) of every row -> LDS (aligned 16-byte pieces, the whole wave), or per-lane dwords
+      float* cur_tile = cbuf ? tile2 : tile;
+      const float* mine = cur_tile + lane * PITCH;
       const int myC = (g4 + (int)((lane * rs + (long)t0 * S) & 3)) & 3;
       if (dma) {
-        constexpr int NB = 5;                    // loads in flight per lane
-#pragma unroll 1
-        for (int j0 = 0; j0 < NPC; j0 += NB) {
-          vf4 v[NB];
-          int off[NB];
-#pragma unroll
-          for (int jj = 0; jj < NB; ++jj) {
-            const int idx = (j0 + jj) * kWave + lane;
-            const int r = idx / NPC, part = idx - r * NPC;
-            const int C = (g4 + (int)((r * rs + (long)t0 * S) & 3)) & 3;
-            off[jj] = (j0 + jj < NPC && 4 * part < C + n * S) ? r * PITCH + 4 * part : -1;
-            const float* src = gs_tile + r * rs + (long)t0 * S - C + 4 * part;      // 16-byte aligned, inside the tile
-            if (off[jj] >= 0) v[jj] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(src));
-          }
-#pragma unroll
-          for (int jj = 0; jj < NB; ++jj)
-            if (off[jj] >= 0) {
-              float* d = tile + off[jj];
-              d[0] = v[jj].x; d[1] = v[jj].y; d[2] = v[jj].z; d[3] = v[jj].w;
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this group's seeds have landed
+        __builtin_amdgcn_wave_barrier();
+        if (gI > 0) request(gI - 1, cbuf ? tile : tile2);    // the other tile was last read two groups ago
       } else {
         const float* src = gs_tile + (lane < nvalid ? lane : nvalid - 1) * rs + (long)t0 * S;
-        for (int i = 0; i < n * S; ++i) mine[myC + i] = src[i];
+        float* d = cur_tile + lane * PITCH + myC;
+        for (int i = 0; i < n * S; ++i) d[i] = src[i];
       }
+      cbuf ^= 1;
       lds_drain();
       // re-run the segment from its checkpoint: pre-step quantities of every step into registers
       float ss[S], park[G][NP], pk[NP];
@@ -500,7 +509,7 @@ static int launch_vjp_regs(const float* x0u, const DynParams& dp, const float* g
   a.tie = tie; a.dp = dp;
   const int TCH = T <= 8 ? 8 : 50;
   const int G = vjp_group(TCH);
-  long w = (long)kWave * vjp_pitch(S, G);
+  long w = (TCH / G > 1 ? 2L : 1L) * kWave * vjp_pitch(S, G);     // two seed tiles where there is a next group to prefetch
   if ((long)kVjpRPP * a.L > w) w = (long)kVjpRPP * a.L;
   a.wlds = (int)((w + 3) & ~3L);
   a.dma_ok = ((reinterpret_cast<uintptr_t>(x0u) | reinterpret_cast<uintptr_t>(gstates) | reinterpret_cast<uintptr_t>(g_x0u)) & 15) == 0;
