@@ -340,6 +340,31 @@ __global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(con
   [[maybe_unused]] float cur = 0.0f;
   if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) cur = s[7];
 
+  const float* gs_tile = a.gstates + b0 * (long)T * S;
+  const long rs = (long)T * S;
+  const int g4 = (int)((reinterpret_cast<uintptr_t>(gs_tile) >> 2) & 3);
+  // The seeds of a group are requested ONE GROUP AHEAD by LDS-DMA (global_load_lds_dwordx4, gathered 16-byte pieces: no
+  // staging VGPRs) into the other of two row tiles: fetched at the top of the group that needs them they cost half the
+  // kernel (157 us without the seeds against 315 us with them, at B = 262144, T = 50) -- the latency of a dependent
+  // global -> register -> LDS round trip per group with two waves per SIMD to hide it.
+  float* tile2 = tile + kWave * PITCH;
+  auto request = [&](int gq, float* dst) {       // seeds of group gq -> dst (asynchronous; retired by vmcnt)
+    const int tq = gq * G;
+    const int nq = (T - tq) < G ? (T - tq) : G;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int idx = j * kWave + lane;
+      const int r = idx / NPC, part = idx - r * NPC;
+      const int C = (g4 + (int)((r * rs + (long)tq * S) & 3)) & 3;
+      const float* src = gs_tile + r * rs + (long)tq * S - C + 4 * part;        // 16-byte aligned, inside the tile
+      if (4 * part < C + nq * S)
+        __builtin_amdgcn_global_load_lds((vgptr_t)src, (vlptr_t)(dst + j * 256), 16, 0, 0);
+    }
+  };
+  const int g_last = (T - 1) / G;                // the last group with steps
+  int cbuf = 0;
+  if (dma) request(g_last, tile);                // in flight during the whole forward pass
+
   // ---- pass 1: forward, one checkpoint per group; the arrays (and the checkpoint list) rotate DOWN circularly:
   //      static register indices inside the rolled loop, natural order after NG groups
   float ck[NG][NP];
@@ -374,33 +399,9 @@ __global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(con
   }
 
   // ---- pass 2: segments in reverse; the group's controls sit at [TCH - G, TCH) ---------------------------------
-  const float* gs_tile = a.gstates + b0 * (long)T * S;
-  const long rs = (long)T * S;
-  const int g4 = (int)((reinterpret_cast<uintptr_t>(gs_tile) >> 2) & 3);
   float lam[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) lam[i] = 0.0f;
-  // The seeds of a group are requested ONE GROUP AHEAD by LDS-DMA (global_load_lds_dwordx4, gathered 16-byte pieces: no
-  // staging VGPRs) into the other of two row tiles: fetched at the top of the group that needs them they cost half the
-  // kernel (157 us without the seeds against 315 us with them, at B = 262144, T = 50) -- the latency of a dependent
-  // global -> register -> LDS round trip per group with two waves per SIMD to hide it.
-  float* tile2 = tile + kWave * PITCH;
-  auto request = [&](int gq, float* dst) {       // seeds of group gq -> dst (asynchronous; retired by vmcnt)
-    const int tq = gq * G;
-    const int nq = (T - tq) < G ? (T - tq) : G;
-#pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      const int idx = j * kWave + lane;
-      const int r = idx / NPC, part = idx - r * NPC;
-      const int C = (g4 + (int)((r * rs + (long)tq * S) & 3)) & 3;
-      const float* src = gs_tile + r * rs + (long)tq * S - C + 4 * part;        // 16-byte aligned, inside the tile
-      if (4 * part < C + nq * S)
-        __builtin_amdgcn_global_load_lds((vgptr_t)src, (vlptr_t)(dst + j * 256), 16, 0, 0);
-    }
-  };
-  const int g_last = (T - 1) / G;                // the last group with steps
-  int cbuf = 0;
-  if (dma) request(g_last, tile);
 #pragma unroll 1
   for (int gI = NG - 1; gI >= 0; --gI) {
     const int t0 = gI * G;
