@@ -133,8 +133,11 @@ struct VjpHArgs {
   float gscale;
 };
 
+#ifndef IRBFN_K2H_MINW
+#define IRBFN_K2H_MINW 4       // waves per SIMD the CT = 2 instance is allocated for (128 VGPRs once the ring is filled by LDS-DMA: 314 -> 303 us)
+#endif
 template <int DC, int BC, int CT>
-__global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const VjpHArgs a) {
+__global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16mfma(const VjpHArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RFQ = vjph_rfq(DC);
   constexpr int QXB = 32 * RFQ * 4;
@@ -192,25 +195,27 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  u4v pre[NP];
-  auto fetch = [&](long qb) {
-    const u4v* src = reinterpret_cast<const u4v*>(a.qblk + (size_t)qb * BLKB);
+  // the next 32-query block lands in the other half of the wave's ring by LDS-DMA (global_load_lds_dwordx4: no
+  // staging VGPRs -- the register copy held 20 -- and no ds_write pass) while the current one is worked on
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto request = [&](long qb, unsigned char* dst) {
+    const unsigned char* src = a.qblk + (size_t)qb * BLKB + lane * 16;
 #pragma unroll
     for (int v = 0; v < NP; ++v)
-      if (v * 64 + lane < NV) pre[v] = src[v * 64 + lane];
+      if (v * 64 + lane < NV) __builtin_amdgcn_global_load_lds((gptr_t)(src + v * 1024), (lptr_t)(dst + v * 1024), 16, 0, 0);
   };
-  auto stash = [&](unsigned char* dst) {
-#pragma unroll
-    for (int v = 0; v < NP; ++v)
-      if (v * 64 + lane < NV) reinterpret_cast<u4v*>(dst)[v * 64 + lane] = pre[v];
+  auto landed = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   };
-  if (qb0 < qb1) { fetch(qb0); stash(mylds); }
-  wave_sync();
+  if (qb0 < qb1) request(qb0, mylds);
+  landed();
   for (long qb = qb0; qb < qb1; ++qb) {
     const unsigned char* cur = mylds + ((qb - qb0) & 1) * BLKB;
     unsigned char* nxt = mylds + ((qb - qb0 + 1) & 1) * BLKB;
     const bool has_next = qb + 1 < qb1;
-    if (has_next) fetch(qb + 1);
+    if (has_next) request(qb + 1, nxt);                       // `nxt` was last read one block ago (wave_sync below)
     constexpr int RQ = 4 / CT;                                // queries per inner step: CT * RQ = 4 transcendentals
     // NOT unrolled: the two halves are independent and hipcc would interleave them (286 VGPRs instead of ~140)
 #pragma unroll 1
@@ -290,8 +295,8 @@ __global__ __launch_bounds__(256, CT == 2 ? 3 : 2) void rbf_vjp_f16mfma(const Vj
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gth, bl, dWl[ct], 0, 0, 0);
       }
     }
-    if (has_next) stash(nxt);
-    wave_sync();
+    wave_sync();                                              // this block's LDS reads are done before `cur` is overwritten
+    landed();
   }
 
   // ---- this wave's totals: d centers / d log_sigs summed over the 4 lane groups (different queries, same centre)
