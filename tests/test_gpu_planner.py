@@ -174,9 +174,11 @@ def test_waypoint_geometry_matches_the_restatement(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode_name,D,T,B", [("st_ks", 7, 5, 4099), ("st_select", 7, 5, 70000), ("st_ks", 7, 1, 1000),
-                                             ("st_ks", 7, 8, 333), ("fullint", 7, 5, 2500), ("frenet", 8, 5, 4099)])
-def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B):
+@pytest.mark.parametrize("mode_name,D,T,B,basis", [
+    ("st_ks", 7, 5, 4099, "gaussian"), ("st_select", 7, 5, 70000, "gaussian"), ("st_ks", 7, 1, 1000, "gaussian"),
+    ("st_ks", 7, 8, 333, "inverse_quadratic"), ("fullint", 7, 5, 2500, "inverse_multiquadric"), ("frenet", 8, 5, 4099, "gaussian"),
+    ("frenet", 8, 5, 129, "inverse_quadratic"), ("frenet", 8, 2, 20000, "inverse_multiquadric")])
+def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B, basis):
     """The planning tick of the narrow nets on the matrix-core kernel (`rbf_tick_f16mfma`: forward + sign flip + roll-out
     by the wave that produced the rows): controls and states equal, bit for bit, the forward followed by the stand-alone
     roll-out kernel -- all four models, T = 1 / 5 / 8, ragged batches, mirror flags, with and without a controls buffer;
@@ -189,7 +191,7 @@ def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B):
     rng = np.random.default_rng(B + T)
     K, O = 512, 2 * T
     lo, hi = [-1.0] * D, [1.0] * D
-    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": "gaussian", "num_regions": 1,
+    cfg = {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": basis, "num_regions": 1,
            "lower_bounds": [[v] for v in lo], "upper_bounds": [[v] for v in hi], "dimension_ranges": [[0] * D],
            "activation_idx": list(range(D)), "delta": [5.0] * D}
     P = {"params": {"rbf_list": {"centers": rng.uniform(-1.2, 1.2, size=(1, K, D)).astype(np.float32),
