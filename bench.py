@@ -414,6 +414,10 @@ def single_gpu_extras(net, params, x, configs, torch):
                     "roofline": {"bound": "hbm", "achieved": rbytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": rbytes / t / 1e9 / PEAK_HBM_GBS},
                     "kernel": "rollout_fwd_pair_kernel<ST_KS> (2 lanes per trajectory, whole-line non-temporal stores)"}
+        # "also report ST-select" (integrate_st_mult: both right-hand sides evaluated, selected by V > 3)
+        t_sel = _time(lambda: dynamics.integrate_st_mult(xu, configs.DYN_PARAMS), max(reps // 2, 5), torch)
+        out[key]["st_select"] = {"traj_per_s": Bt / t_sel, "us": t_sel * 1e6, "hbm_GBs": rbytes / t_sel / 1e9,
+                                 "hbm_frac": rbytes / t_sel / 1e9 / PEAK_HBM_GBS}
         del xu, states
     # config 4 forward alone at the per-GPU share, by execution unit
     card4 = configs.model_card(4)
