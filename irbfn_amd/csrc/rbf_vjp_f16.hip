@@ -66,10 +66,10 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
   const float sh = sg * somax;
   if (blockIdx.x == 0 && lane == 0) { scales[0] = sg; scales[1] = sh; }
   // x rows + gate (model.py:42-95, single region)
+  float gm = 0.0f;                               // gamma of query q0 + lane (lanes >= 32: 0)
   if (lane < 32) {
     const long q = q0 + lane;
     float* row = reinterpret_cast<float*>(p) + lane * RFQ;
-    float gm = 0.0f;
     if (q < B) {
       gm = gt.n_ranges > 0 ? 1.0f : 0.0f;
       for (int d = 0; d < gt.nsplit && gt.n_ranges > 0; ++d) {
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
     gA[(s * 2 + 1) * 64 + lane] = lo;
   }
   // A operand of the dW MFMA (16x16x16, one per 16-query half): rows = outputs n, k = 4 g + j <-> query 16 s + 4 g + j
-  // (the lane's own 4 queries of that half), scaled by 1 / s_g
+  // (the lane's own 4 queries of that half), scaled by gamma / s_g: d W = (gamma Phi)^T g = Phi^T (gamma g), so the main kernel
+  // hands the basis values to the MFMA as they leave the transcendental unit (one multiply per pair less)
   h4v* gT = reinterpret_cast<h4v*>(p + 32 * RFQ * 4 + 2048);         // [s][part][lane] x 4 halfs
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -108,8 +109,9 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long q = q0 + 16 * s + 4 * g + j;
+      const float gq = __shfl(gm, 16 * s + 4 * g + j);
       float v = 0.0f;
-      if (q < B && n < O) v = gout[q * O + n] / sg;
+      if (q < B && n < O) v = gq * gout[q * O + n] / sg;
       _Float16 h, l;
       split_static_f16(v, h, l);
       hi[j] = h;
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
   const float sg = a.scales[0], sh = a.scales[1];
   // s_h times the constant of dphi/dd2 (gaussian family: -a; inverse quadratic: -1; inverse multiquadric: -1/2)
   // (and 2^-30: both operands of the hbar product carry 2^15)
-  const float shk = sh * (1.0f / (kWScale * kWScale)) * (BC == BC_GAUSS ? -a.gscale : (BC == BC_IQ ? -1.0f : -0.5f));
+  // (and 2^-14 per power of P = 2^14 phi in dphi/dd2: the basis values stay in the scale the dW MFMA wants)
+  const float shk = sh * (1.0f / (kWScale * kWScale)) * (BC == BC_GAUSS ? -a.gscale * kPhiInv
+                                                          : (BC == BC_IQ ? -kPhiInv * kPhiInv : -0.5f * kPhiInv * kPhiInv * kPhiInv));
 
   float c[CT][DC], sc[CT], s2m2[CT];
   h4v wth[CT], wtl[CT];
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
     const float* rp = a.rec + (size_t)cid * a.S;
 #pragma unroll
     for (int j = 0; j < DC; ++j) c[ct][j] = rp[j];
-    sc[ct] = rp[DC];
+    // argument of the transcendental for P = 2^14 phi: gaussian 2^(r2 sc + 14); 1 / (2^-14 (1 + d2)); rsqrt(2^-28 (1 + d2))
+    sc[ct] = rp[DC] * (BC == BC_GAUSS ? 1.0f : (BC == BC_IQ ? kPhiInv : kPhiInv * kPhiInv));
     s2m2[ct] = -2.0f * a.sig2[cid];                          // -2 / sigma^2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
       float hq[CT][4];                                        // 2^kPhiExp gamma phi of this lane's 4 queries of the half
 #pragma unroll
       for (int r0 = 0; r0 < 4; r0 += RQ) {
-        float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], gm16[RQ], kq[RQ];
+        float diff[RQ][CT][DC], r2[RQ][CT], t[RQ * CT], kq[RQ];
 #pragma unroll
         for (int u = 0; u < RQ; ++u) {
           const float* xr = reinterpret_cast<const float*>(cur) + (16 * s + 4 * g + r0 + u) * RFQ;
@@ -247,7 +252,6 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
             const f4v rr = *reinterpret_cast<const f4v*>(xr + 4 * v);
             xv[4 * v] = rr.x; xv[4 * v + 1] = rr.y; xv[4 * v + 2] = rr.z; xv[4 * v + 3] = rr.w;
           }
-          gm16[u] = xv[RFQ - 1] * kPhiScale;
           kq[u] = xv[RFQ - 1] * shk;                          // gamma * s_h * (basis constant of dphi/dd2)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
@@ -258,7 +262,8 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
               acc = __builtin_fmaf(diff[u][ct][j], diff[u][ct][j], acc);
             }
             r2[u][ct] = acc;
-            t[u * CT + ct] = basis_arg<BC>(acc, sc[ct]);
+            t[u * CT + ct] = BC == BC_GAUSS ? __builtin_fmaf(acc, sc[ct], (float)kPhiExp)
+                                            : __builtin_fmaf(acc, sc[ct], BC == BC_IQ ? kPhiInv : kPhiInv * kPhiInv);
           }
         }
         trans_block<BC, RQ * CT>(t);                          // phi of the step's 4 pairs
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const int r = r0 + u;
-            const float phi = t[u * CT + ct];
-            hq[ct][r] = phi * gm16[u];
+            const float phi = t[u * CT + ct];                 // P = 2^14 phi
+            hq[ct][r] = phi;
             // tt = hbar * gamma * dphi/dd2:  gaussian -a phi | IQ -phi^2 | IMQ -phi^3 / 2  (constants folded into kq)
             float pw = phi;
             if constexpr (BC == BC_IQ) pw = phi * phi;
