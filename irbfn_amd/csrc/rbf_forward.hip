@@ -140,6 +140,10 @@ static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   int nw = want < 1 ? 1 : (want > 16 ? 16 : (int)want);
   nw = pow2_floor(nw);
   while (nw > 1 && net->N / nw < 32) nw /= 2;
+  // small nets (the reference's trained ones have 1000-1280 centres): fewer, longer waves once the launch still has
+  // 8 waves per SIMD -- the per-block prologue / 16-wave reduction costs as much as 80 centres per wave
+  // (128-region net, B = 65536: 95 -> 75 us; 12-region Frenet net 64 -> 49 us)
+  while (nw > 1 && net->N / nw < 128 && tiles * (nw / 2) >= 8192) nw /= 2;
   while (nw * kWave > max_threads) nw /= 2;
   nw = opt_or(net, IRBFN_OPT_FWD_NW, nw);
   if (nw * kWave > max_threads) nw = max_threads / kWave;
