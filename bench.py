@@ -452,6 +452,31 @@ def single_gpu_extras(net, params, x, configs, torch):
         "one_launch_minus_forward_us": (med(t1) - med(tf)) * 1e6, "traj_per_s": 32768 / med(t1), "kernel": k1,
         "what": "forward O=100 + 50-step ST-kinematic roll-out, controls and states written; medians of 3 interleaved rounds x 20"}
     del x4, s4
+    # the reference's own trained planners (decoded checkpoints committed as fixtures under tests/golden/; 1000-1280 centres,
+    # one / 12 / 128 regions): forward at B = 65536 uniform in-range queries
+    import json as _json
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    trained = {}
+    for run in ("dnmpc_1regions_newdata_oldintloss_nomirror_highk", "dnmpc_128regions", "dnmpc_12regions_frenet_l1_bigdata"):
+        fz, fj = os.path.join(gdir, f"ckpt_{run}.npz"), os.path.join(gdir, f"ckpt_{run}.json")
+        if not (os.path.exists(fz) and os.path.exists(fj)):
+            continue
+        z, cfg_t = np.load(fz), _json.load(open(fj))
+        pt = {"params": {"rbf_list": {"centers": z["centers"].astype(np.float32), "log_sigs": z["log_sigs"].astype(np.float32)},
+                         "linear": {"kernel": z["kernel"].astype(np.float32), "bias": z["bias"].astype(np.float32)}}}
+        nt = WCRBFNet.from_config(cfg_t)
+        nt.bind(distributed.params_to_device(pt))
+        ns = len(cfg_t["activation_idx"])
+        lo_t = np.array([min(cfg_t["lower_bounds"][d]) for d in range(ns)]); hi_t = np.array([max(cfg_t["upper_bounds"][d]) for d in range(ns)])
+        rng_t = np.random.default_rng(1)
+        xq = np.hstack([rng_t.uniform(lo_t, hi_t, size=(65536, ns)),
+                        rng_t.normal(size=(65536, cfg_t["in_features"] - ns)) * 0.1]).astype(np.float32)
+        xt_ = torch.from_numpy(xq).cuda()
+        tt_ = _time(lambda: nt(xt_), 30, torch)
+        trained[run] = {"us": tt_ * 1e6, "evals_per_s": 65536 / tt_, "regions": cfg_t["num_regions"],
+                        "centres": cfg_t["num_regions"] * cfg_t["num_kernels"], "kernel": nt.last_launch()["kernel"]}
+        del xt_, nt
+    out["reference_trained_checkpoints_forward_B65536"] = trained
     # BASELINE config 5 ("fp32 vs bf16, reduction cast as MFMA GEMM, utilisation reported"): 16384-centre inverse-
     # multiquadric net, B = 2^20 -- fp32 VALU kernel (K1) vs K1h at float32 accuracy (hi/lo f16 operand pairs), with
     # plain f16 operands and with plain bf16 operands
