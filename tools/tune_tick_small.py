@@ -12,7 +12,11 @@ for B in (1, 8, 64, 256):
     s0 = torch.from_numpy(configs.initial_state_from_query(x.cpu().numpy())).cuda()
     def tick(): return plan_batch(net, P, x, s0, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_SELECT)
     def fwd(): return net.apply(P, x)
-    for name, fn in (("forward only", fwd), ("fused tick", tick)):
+    from irbfn_amd import dynamics
+    def two():
+        u = net.apply(P, x)
+        return dynamics.integrate_st_mult(torch.cat([s0, u], dim=1), configs.DYN_PARAMS)
+    for name, fn in (("forward only", fwd), ("fused tick", tick), ("forward + cat + stand-alone roll-out", two)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
