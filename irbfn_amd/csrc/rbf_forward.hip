@@ -152,11 +152,12 @@ static int run_forward(irbfn_net* net, FwdArgs& a, bool roll, hipStream_t s) {
   size_t stage = (size_t)ROWS * net->D;
   if (gated) stage += (size_t)net->nsplit * net->max_ranges * ROWS;
   size_t red = (size_t)nw * Q * OC * (kWave + 1) + ROWS;
-  if (roll) red += (size_t)ROWS * net->O;
+  const size_t roll_floats = roll ? (size_t)ROWS * (net->O + 65) : 0;      // controls + the states staging tile (pitch 65)
+  red += roll_floats;
   size_t lds = (stage > red ? stage : red) * sizeof(float);
   while (lds > 160 * 1024 && nw > 1) {
     nw /= 2;
-    red = (size_t)nw * Q * OC * (kWave + 1) + ROWS + (roll ? (size_t)ROWS * net->O : 0);
+    red = (size_t)nw * Q * OC * (kWave + 1) + ROWS + roll_floats;
     lds = (stage > red ? stage : red) * sizeof(float);
   }
   if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
@@ -395,6 +396,7 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
     return launch_rollout_forward_split(mode, state0, controls, dp, states, B, T, s);
   }
   if (net->bclass == BC_GENERIC) return IRBFN_ERR_UNSUPPORTED;
+  if (T * rollout_state_dim(mode) > 64) return IRBFN_ERR_UNSUPPORTED;      // the epilogue's staging tile holds 64 floats per row
   FwdArgs a;
   fill_args(net, a, x, controls, B);
   a.state0 = state0;

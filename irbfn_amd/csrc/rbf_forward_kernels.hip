@@ -49,6 +49,7 @@ __device__ __forceinline__ void pair_body(const float* __restrict__ rp_, const f
 
 // G centres at once: G distances, then the G*Q transcendentals as ONE block (rbf_forward.h: an isolated
 // transcendental costs ~4x a batched one), then the G weight rows.  Fast bases only.
+constexpr int kRollStagePitch = 65;   // ROLL: floats per row of the states staging tile (T * S <= 64), odd
 #ifndef IRBFN_FWD_G
 #define IRBFN_FWD_G 4
 #endif
@@ -256,17 +257,21 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
     __syncthreads();
   }
 
-  // ---- fused roll-out: the controls stay in LDS (batched IRBFNPlanner.plan, irbfn_planner.py:205-212)
+  // ---- fused roll-out: the controls stay in LDS (batched IRBFNPlanner.plan, irbfn_planner.py:205-212); the T x S states
+  // of the block's rows -- one contiguous piece of HBM -- are staged row by row in LDS and leave as coalesced dwords
+  // (round 1 stored them per lane, 4 bytes at a stride of T x S x 4)
   if constexpr (ROLL) {
     const int T = a.T;
+    const int Sdim = (a.mode == IRBFN_ROLLOUT_FULLINT) ? 5 : (a.mode == IRBFN_ROLLOUT_FRENET_LS ? 8 : 7);
+    float* stage = ctrl + ROWS * a.O;            // [ROWS][kRollStagePitch]
     for (int row = tid; row < nvalid; row += nthreads) {
       const float* u = ctrl + row * a.O;
       const long b = row0 + row;
+      float* o = stage + row * kRollStagePitch;
       if (a.mode == IRBFN_ROLLOUT_ST_SELECT || a.mode == IRBFN_ROLLOUT_ST_KS) {
         float s[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) s[i] = a.state0[b * 7 + i];
-        float* o = a.states + b * (long)T * 7;
         for (int t = 0; t < T; ++t) {
           if (a.mode == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, u[t], u[T + t], a.dp);
           else st_step<false>(s, u[t], u[T + t], a.dp);
@@ -277,7 +282,6 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
         float s[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] = a.state0[b * 8 + i];
-        float* o = a.states + b * (long)T * 8;
         for (int t = 0; t < T; ++t) {
           frenet_step(s, u[t], u[T + t], a.dp);
 #pragma unroll
@@ -285,13 +289,19 @@ __global__ __launch_bounds__((OP * Q > 48) ? 512 : 1024) void rbf_fwd_qlane(cons
         }
       } else if (a.mode == IRBFN_ROLLOUT_FULLINT) {
         float s[5] = {0.0f, 0.0f, 0.0f, clipf(a.state0[b], 0.0f, 7.0f), 0.0f};   // train_nmpc.py:319
-        float* o = a.states + b * (long)T * 5;
         for (int t = 0; t < T; ++t) {
           fullint_step(s, u[t], u[T + t]);
 #pragma unroll
           for (int i = 0; i < 5; ++i) o[t * 5 + i] = s[i];
         }
       }
+    }
+    __syncthreads();
+    const int rowf = T * Sdim;                   // floats per trajectory (<= 64)
+    float* gout = a.states + row0 * (long)rowf;
+    for (int idx = tid; idx < nvalid * rowf; idx += nthreads) {
+      const int r = idx / rowf, c = idx - r * rowf;
+      gout[idx] = stage[r * kRollStagePitch + c];
     }
   }
 }
