@@ -37,7 +37,8 @@ def to_device_f32(a, torch, device=None):
     if isinstance(a, torch.Tensor):
         t = a
     else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+        arr = np.ascontiguousarray(np.asarray(a))
+        t = torch.from_numpy(arr) if arr.flags.writeable else torch.tensor(arr)    # read-only arrays: torch wants a copy
     if t.dtype != torch.float32:
         t = t.to(torch.float32)     # float64 checkpoints are cast on load
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -189,8 +190,11 @@ class WCRBFNet:
         for a in leaves:
             if isinstance(a, torch.Tensor):
                 fp.append((id(a), a.data_ptr(), a._version))
+            elif isinstance(a, np.ndarray) and not a.flags.writeable and (a.base is None or not getattr(a.base, "flags", a.flags).writeable):
+                # a read-only array (what np.asarray(jax_array) hands out, or setflags(write=False)) cannot change unseen
+                fp.append((id(a), a.ctypes.data, a.shape, a.strides, str(a.dtype)))
             else:
-                return ()           # numpy can be mutated in place unseen: always re-upload
+                return ()           # a writable numpy array can be mutated in place unseen: always re-upload
         return tuple(fp)
 
     def bind(self, params: dict) -> "WCRBFNet":

@@ -611,3 +611,24 @@ def test_cluster_wcrbfnet_forward(gpu, R, K, O, B):
     bad = {"params": dict(params["params"], cluster={"kernel": np.zeros((D, R + 1), np.float32), "bias": np.zeros(R + 1, np.float32)})}
     with pytest.raises(ValueError):
         net.apply(bad, x)
+
+
+def test_bind_reuploads_writable_numpy_but_not_readonly(gpu):
+    """apply(params, x) with NumPy leaves re-uploads them on every call (they can be mutated in place unseen) unless
+    they are read-only -- what np.asarray(jax_array) hands out; torch leaves are tracked by version."""
+    cfg, P, x = configs.model_card(1), configs.synth_params(1), configs.synth_queries(1, B=100)
+    net = WCRBFNet.from_config(cfg)
+    a = net.apply(P, x)
+    P["params"]["linear"]["bias"] += 1.0                        # in-place change of a writable leaf must be seen
+    b = net.apply(P, x)
+    assert np.abs((b - a) - 1.0).max() < 1e-5
+    ro = {"params": {g: {n: np.array(v) for n, v in d.items()} for g, d in P["params"].items()}}
+    for d in ro["params"].values():
+        for v in d.values():
+            v.setflags(write=False)
+    import torch
+    net.apply(ro, x)
+    fp = dict(net._bound_fp)
+    assert fp[torch.cuda.current_device()] != ()                # fingerprinted: the next apply() skips the upload
+    c = net.apply(ro, x)
+    assert net._bound_fp == fp and np.array_equal(c, b)
