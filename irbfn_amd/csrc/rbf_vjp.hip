@@ -64,36 +64,48 @@ __device__ __forceinline__ float dphi_dd2(float phi, float d2, float gscale, int
 // stream (s_load_dwordx16 + x4) without per-element bounds branches:
 //   qrec[b] = { x[b, 0..D) (padded to DC), gamma[b] (R == 1; model.py:42-95), g[b, 0..O) (padded to OP) }.
 // For R > 1 the full gamma[B][R] matrix is written as well (per-lane region weights).
-__global__ __launch_bounds__(64) void vjp_pack_queries_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                              float* __restrict__ qrec, float* __restrict__ gamma,
-                                                              GateTables gt, long B, int D, int DC, int O, int OP,
-                                                              int QS, int R) {
+__global__ __launch_bounds__(256) void vjp_pack_queries_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               float* __restrict__ qrec, float* __restrict__ gamma,
+                                                               GateTables gt, long B, int D, int DC, int O, int OP,
+                                                               int QS, int R) {
+  // 64 queries per block, 256 threads; every global store runs over consecutive addresses (the first version gave a lane
+  // one query: its R region weights went out as R dwords at a stride of R -- 87 us of the 128-region net's VJP at B = 80000)
   extern __shared__ float gtab[];                 // [E][64]
-  const int lane = threadIdx.x;
-  const long b = (long)blockIdx.x * kWave + lane;
-  const long bb = b < B ? b : B - 1;
+  const int tid = threadIdx.x;
+  const long b0 = (long)blockIdx.x * kWave;
+  const long left = B - b0;
+  const int nv = left < kWave ? (int)left : kWave;
   const int E = gt.nsplit * gt.max_ranges;
-  for (int e = 0; e < E; ++e) {
+  for (int idx = tid; idx < E * kWave; idx += 256) {
+    const int e = idx >> 6, q = idx & (kWave - 1);
     const int d = e / gt.max_ranges;
-    gtab[e * kWave + lane] = gate_factor(x[bb * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+    const long bb = b0 + (q < nv ? q : nv - 1);
+    gtab[idx] = gate_factor(x[bb * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
   }
-  if (b >= B) return;
-  float* q = qrec + b * QS;
-  for (int j = 0; j < DC; ++j) q[j] = j < D ? x[b * D + j] : 0.0f;
-  float g0 = 0.0f;
-  for (int r = 0; r < R; ++r) {
-    float gm = 0.0f;
-    if (r < gt.n_ranges) {
-      gm = 1.0f;
-      for (int d = 0; d < gt.nsplit; ++d)
-        gm *= gtab[(d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d]) * kWave + lane];
+  __syncthreads();
+  auto region_weight = [&](int q, int r) {        // model.py:70, 88-93
+    if (r >= gt.n_ranges) return 0.0f;
+    float gm = 1.0f;
+    for (int d = 0; d < gt.nsplit; ++d) gm *= gtab[(d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d]) * kWave + q];
+    return gm;
+  };
+  // packed records: { x (padded to DC), gamma of region 0, g (padded to OP), zeros up to QS }
+  float* qb = qrec + b0 * QS;
+  for (int idx = tid; idx < nv * QS; idx += 256) {
+    const int q = idx / QS, j = idx - q * QS;
+    float v = 0.0f;
+    if (j < D) v = x[(b0 + q) * D + j];
+    else if (j == DC) v = region_weight(q, 0);
+    else if (j > DC && j - DC - 1 < O) v = g[(b0 + q) * O + (j - DC - 1)];
+    qb[idx] = v;
+  }
+  if (R > 1) {                                    // the full gamma[B][R] matrix (per-lane region weights of K2)
+    float* gb = gamma + b0 * R;
+    for (int idx = tid; idx < nv * R; idx += 256) {
+      const int q = idx / R, r = idx - q * R;
+      gb[idx] = region_weight(q, r);
     }
-    if (r == 0) g0 = gm;
-    if (R > 1) gamma[b * R + r] = gm;
   }
-  q[DC] = g0;
-  for (int o = 0; o < OP; ++o) q[DC + 1 + o] = o < O ? g[b * O + o] : 0.0f;
-  for (int j = DC + 1 + OP; j < QS; ++j) q[j] = 0.0f;
 }
 
 template <int D, int OP, int BC, bool GATED>
@@ -200,30 +212,49 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
   }
 }
 
-// reduce the slabs over query slices (and, for d kernel, over regions); one thread per output value
-__global__ void vjp_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_centers,
-                                  float* __restrict__ g_log_sigs, float* __restrict__ g_kernel, int QSB,
-                                  int V, int Npad, int N, int K, int R, int D, int DC, int O) {
+// Reduce the slabs.  Stage 1: one thread per (value v, centre n) sums the query slices in slice order (consecutive threads
+// = consecutive centres: coalesced) -> d centers, d log_sigs, and the per-CENTRE Dense gradient, which for one region IS
+// d kernel and for R > 1 goes back into slab 0 (only this thread touches those words).  Stage 2 (R > 1): d kernel[k, o] =
+// sum over the regions of the per-centre values, one wave per output, fixed tree.  (Round 1 summed R x QSB terms per
+// output value in ONE thread: 100 threads x 128 regions x 24 slices of dependent loads = 2.2 ms of the 2.6 ms training
+// step of the reference's 128-region net at its batch size of 80000.)
+__global__ __launch_bounds__(256) void vjp_reduce_kernel(float* __restrict__ part, float* __restrict__ g_centers,
+                                                         float* __restrict__ g_log_sigs, float* __restrict__ g_kernel, int QSB,
+                                                         int V, int Npad, int N, int K, int R, int D, int DC, int O) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n_c = (long)N * D, n_l = N, n_k = (long)K * O;
-  if (i < n_c) {
-    const int n = (int)(i / D), j = (int)(i - (long)n * D);
-    float s = 0.0f;
-    for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + j) * Npad + n];
-    g_centers[i] = s;
-  } else if (i < n_c + n_l) {
-    const int n = (int)(i - n_c);
-    float s = 0.0f;
-    for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + DC) * Npad + n];
-    g_log_sigs[n] = s;
-  } else if (i < n_c + n_l + n_k) {
-    const long t = i - n_c - n_l;
-    const int k = (int)(t / O), o = (int)(t - (long)k * O);
-    float s = 0.0f;
-    for (int r = 0; r < R; ++r)
-      for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + DC + 1 + o) * Npad + (size_t)r * K + k];
-    g_kernel[t] = s;
+  if (i >= (long)V * N) return;
+  const int v = (int)(i / N), n = (int)(i - (long)v * N);
+  if ((v >= D && v < DC) || v > DC + O) return;            // padded coordinate / output slots
+  float s = 0.0f;
+  for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + v) * Npad + n];
+  if (v < D) g_centers[(size_t)n * D + v] = s;
+  else if (v == DC) g_log_sigs[n] = s;
+  else if (R == 1) g_kernel[(size_t)n * O + (v - DC - 1)] = s;
+  else part[(size_t)v * Npad + n] = s;                      // slab 0
+}
+
+__global__ __launch_bounds__(64) void vjp_reduce_regions_kernel(const float* __restrict__ part, float* __restrict__ g_kernel,
+                                                                int Npad, int K, int R, int DC, int O) {
+  const int k = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
+  float s = 0.0f;
+  for (int r = lane; r < R; r += kWave) s += part[(size_t)(DC + 1 + o) * Npad + (size_t)r * K + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);      // fixed tree: deterministic
+  if (lane == 0) g_kernel[(size_t)k * O + o] = s;
+}
+
+int launch_vjp_reduce(const irbfn_net* net, float* part, float* g_centers, float* g_log_sigs, float* g_kernel, int QSB, int V,
+                      int Npad, hipStream_t s) {
+  const long total = (long)V * net->N;
+  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, g_centers, g_log_sigs,
+                     g_kernel, QSB, V, Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  if (net->R > 1) {
+    hipLaunchKernelGGL(vjp_reduce_regions_kernel, dim3(net->K, net->O), dim3(kWave), 0, s, part, g_kernel, Npad, net->K, net->R,
+                       net->DC, net->O);
+    IRBFN_HIP_CHECK(hipGetLastError());
   }
+  return IRBFN_OK;
 }
 
 // d bias[o] = sum_b g[b,o]: per-block column sums, then one block finishes (fixed order)
@@ -604,9 +635,8 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     int rch = launch_vjp_f16(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks,
                              scales, part, p.QSB, p.Npad, p.CT, s);
     if (rch != IRBFN_OK) return rch;
-    hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total_h + 255) / 256)), dim3(256), 0, s, part, g_centers,
-                       g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
-    IRBFN_HIP_CHECK(hipGetLastError());
+    rch = launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s);
+    if (rch != IRBFN_OK) return rch;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
     IRBFN_HIP_CHECK(hipGetLastError());
     return IRBFN_OK;
@@ -616,7 +646,7 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   {
     const size_t glds = (size_t)net->nsplit * net->max_ranges * kWave * sizeof(float);
     if (glds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(vjp_pack_queries_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), glds, s, x, gout,
+    hipLaunchKernelGGL(vjp_pack_queries_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(256), glds, s, x, gout,
                        qrec, gamma, net->gate(), (long)B, net->D, net->DC, net->O, net->OP, p.QS, net->R);
     IRBFN_HIP_CHECK(hipGetLastError());
   }
@@ -637,10 +667,8 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   }
   if (rc != IRBFN_OK) return rc;
 
-  const long total = n_c + n_l + n_k;
-  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, g_centers,
-                     g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
-  IRBFN_HIP_CHECK(hipGetLastError());
+  rc = launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s);
+  if (rc != IRBFN_OK) return rc;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
                      (long)B, net->O, p.rows_per_block, (float*)nullptr);
   IRBFN_HIP_CHECK(hipGetLastError());
