@@ -475,6 +475,18 @@ def single_gpu_extras(net, params, x, configs, torch):
         tt_ = _time(lambda: nt(xt_), 30, torch)
         trained[run] = {"us": tt_ * 1e6, "evals_per_s": 65536 / tt_, "regions": cfg_t["num_regions"],
                         "centres": cfg_t["num_regions"] * cfg_t["num_kernels"], "kernel": nt.last_launch()["kernel"]}
+        if cfg_t["out_features"] == 10 and cfg_t["in_features"] == 7:
+            # the reference's training step at its own batch size (batch_size: 80000 in scripts/configs/*.yaml):
+            # train_step_fullint = forward, loss seeds through the 5-step bicycle, parameter VJP, clip + Adam
+            Bt_ = 80000
+            xb = torch.from_numpy(rng_t.uniform(lo_t, hi_t, size=(Bt_, 7)).astype(np.float32)).cuda()
+            yb = torch.from_numpy(np.hstack([rng_t.normal(size=(Bt_, 5)) * 2, rng_t.normal(size=(Bt_, 5)) * 0.5]).astype(np.float32)).cuda()
+            st_box = [train.TrainState.create(nt, pt, lr=1e-3, max_grad_norm=1.0)]
+            def _step():
+                st_box[0], _ = train.train_step_fullint(st_box[0], xb, yb)
+            ts_ = _time(_step, 20, torch)
+            trained[run]["train_step_fullint_B80000"] = {"us": ts_ * 1e6, "evals_per_s": Bt_ / ts_}
+            del xb, yb, st_box
         del xt_, nt
     out["reference_trained_checkpoints_forward_B65536"] = trained
     # BASELINE config 5 ("fp32 vs bf16, reduction cast as MFMA GEMM, utilisation reported"): 16384-centre inverse-

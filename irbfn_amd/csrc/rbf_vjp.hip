@@ -70,12 +70,17 @@ __global__ __launch_bounds__(256) void vjp_pack_queries_kernel(const float* __re
                                                                int QS, int R) {
   // 64 queries per block, 256 threads; every global store runs over consecutive addresses (the first version gave a lane
   // one query: its R region weights went out as R dwords at a stride of R -- 87 us of the 128-region net's VJP at B = 80000)
-  extern __shared__ float gtab[];                 // [E][64]
+  extern __shared__ float gtab[];                 // [E][64] gate factors, then [n_ranges][nsplit] table rows (as E * 64 offsets)
   const int tid = threadIdx.x;
   const long b0 = (long)blockIdx.x * kWave;
   const long left = B - b0;
   const int nv = left < kWave ? (int)left : kWave;
   const int E = gt.nsplit * gt.max_ranges;
+  int* rows = reinterpret_cast<int*>(gtab + E * kWave);
+  for (int idx = tid; idx < gt.n_ranges * gt.nsplit; idx += 256) {
+    const int d = idx % gt.nsplit;
+    rows[idx] = (d * gt.max_ranges + gt.dim_ranges[idx]) * kWave;
+  }
   for (int idx = tid; idx < E * kWave; idx += 256) {
     const int e = idx >> 6, q = idx & (kWave - 1);
     const int d = e / gt.max_ranges;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void vjp_pack_queries_kernel(const float* __re
   auto region_weight = [&](int q, int r) {        // model.py:70, 88-93
     if (r >= gt.n_ranges) return 0.0f;
     float gm = 1.0f;
-    for (int d = 0; d < gt.nsplit; ++d) gm *= gtab[(d * gt.max_ranges + gt.dim_ranges[r * gt.nsplit + d]) * kWave + q];
+    for (int d = 0; d < gt.nsplit; ++d) gm *= gtab[rows[r * gt.nsplit + d] + q];
     return gm;
   };
   // packed records: { x (padded to DC), gamma of region 0, g (padded to OP), zeros up to QS }
@@ -644,7 +649,7 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
 
   float* qrec = reinterpret_cast<float*>(base + p.off_qrec);
   {
-    const size_t glds = (size_t)net->nsplit * net->max_ranges * kWave * sizeof(float);
+    const size_t glds = ((size_t)net->nsplit * net->max_ranges * kWave + (size_t)net->gate().n_ranges * net->nsplit) * sizeof(float);
     if (glds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vjp_pack_queries_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(256), glds, s, x, gout,
                        qrec, gamma, net->gate(), (long)B, net->D, net->DC, net->O, net->OP, p.QS, net->R);
