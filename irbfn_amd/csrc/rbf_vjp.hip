@@ -226,12 +226,19 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
 __global__ __launch_bounds__(256) void vjp_reduce_kernel(float* __restrict__ part, float* __restrict__ g_centers,
                                                          float* __restrict__ g_log_sigs, float* __restrict__ g_kernel, int QSB,
                                                          int V, int Npad, int N, int K, int R, int D, int DC, int O) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)V * N) return;
-  const int v = (int)(i / N), n = (int)(i - (long)v * N);
-  if ((v >= D && v < DC) || v > DC + O) return;            // padded coordinate / output slots
+  // block = (value v, 64 consecutive centres) x 4 slice groups: thread (sg, l) sums slices sg, sg + 4, ... in order, the
+  // four partial sums are added in a fixed order (small nets have few centre groups and hundreds of slices)
+  __shared__ float sm[4][kWave];
+  const int l = threadIdx.x & (kWave - 1), sg = threadIdx.x >> 6;
+  const int v = blockIdx.y, n = blockIdx.x * kWave + l;
+  if ((v >= D && v < DC) || v > DC + O) return;            // padded coordinate / output slots (whole block)
   float s = 0.0f;
-  for (int q = 0; q < QSB; ++q) s += part[((size_t)q * V + v) * Npad + n];
+  if (n < N)
+    for (int q = sg; q < QSB; q += 4) s += part[((size_t)q * V + v) * Npad + n];
+  sm[sg][l] = s;
+  __syncthreads();
+  if (sg != 0 || n >= N) return;
+  s = (sm[0][l] + sm[1][l]) + (sm[2][l] + sm[3][l]);
   if (v < D) g_centers[(size_t)n * D + v] = s;
   else if (v == DC) g_log_sigs[n] = s;
   else if (R == 1) g_kernel[(size_t)n * O + (v - DC - 1)] = s;
@@ -250,9 +257,8 @@ __global__ __launch_bounds__(64) void vjp_reduce_regions_kernel(const float* __r
 
 int launch_vjp_reduce(const irbfn_net* net, float* part, float* g_centers, float* g_log_sigs, float* g_kernel, int QSB, int V,
                       int Npad, hipStream_t s) {
-  const long total = (long)V * net->N;
-  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, g_centers, g_log_sigs,
-                     g_kernel, QSB, V, Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
+  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((net->N + kWave - 1) / kWave), V), dim3(256), 0, s, part, g_centers,
+                     g_log_sigs, g_kernel, QSB, V, Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
   IRBFN_HIP_CHECK(hipGetLastError());
   if (net->R > 1) {
     hipLaunchKernelGGL(vjp_reduce_regions_kernel, dim3(net->K, net->O), dim3(kWave), 0, s, part, g_kernel, Npad, net->K, net->R,
