@@ -285,14 +285,17 @@ int irbfn_net_forward_gamma(irbfn_net* net, const float* x_dev, const float* gam
  *   dgamma[b,r] = sum_k (gout W^T)[b,k] phi[b,r,k]   (O <= 16).
  * irbfn_cluster_gate_vjp: softmax + Dense backward of the gate (model.py:402-404): dlogits = gamma * (dgamma -
  *   <gamma, dgamma>) [+ glogits_dev, the direct cotangent of the logits; may be NULL] -> g_wc [D,R], g_bc [R];
- *   dlogits_dev [B,R] is scratch / output.
+ *   dlogits_dev [B,R] is scratch / output; workspace_dev: irbfn_cluster_gate_vjp_workspace_bytes(D, R) bytes (per-block
+ *   partial sums, added in block order: deterministic).
  * irbfn_softmax_xent: optax.softmax_cross_entropy(logits, labels).mean() (train_nmpc_frenet.py:431) -> loss (added to
  *   *loss_dev if accumulate != 0) and glogits = d loss / d logits; partials_dev: irbfn_train_loss_partials() floats. */
 int irbfn_net_vjp_gamma(irbfn_net* net, const float* x_dev, const float* gamma_dev, const float* gout_dev,
                         float* g_centers_dev, float* g_log_sigs_dev, float* g_kernel_dev, float* g_bias_dev, float* dgamma_dev,
                         int64_t B, void* workspace_dev, int64_t workspace_bytes, void* stream);
+int64_t irbfn_cluster_gate_vjp_workspace_bytes(int D, int R);
 int irbfn_cluster_gate_vjp(const float* x_dev, const float* gamma_dev, const float* dgamma_dev, const float* glogits_dev,
-                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R, void* stream);
+                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R,
+                           void* workspace_dev, int64_t workspace_bytes, void* stream);
 int irbfn_softmax_xent(const float* logits_dev, const float* labels_dev, float* glogits_dev, float* loss_dev,
                        float* partials_dev, int accumulate, int64_t B, int R, void* stream);
 

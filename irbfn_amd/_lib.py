@@ -58,7 +58,8 @@ SIGNATURES = {
     "irbfn_net_tick_needs_controls": (_i, [_vp, _i, _i64, _i]),
     "irbfn_net_forward_gamma": (_i, [_vp, _fp, _fp, _fp, _i64, _vp]),
     "irbfn_net_vjp_gamma": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _vp, _i64, _vp]),
-    "irbfn_cluster_gate_vjp": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp]),
+    "irbfn_cluster_gate_vjp_workspace_bytes": (_i64, [_i, _i]),
+    "irbfn_cluster_gate_vjp": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _vp, _i64, _vp]),
     "irbfn_softmax_xent": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i64, _i, _vp]),
     "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),
     "irbfn_mlp_head_vjp_workspace_bytes": (_i64, [_i, _i, _i]),

@@ -204,12 +204,19 @@ int irbfn_net_vjp_gamma(irbfn_net* net, const float* x_dev, const float* gamma_d
   return rc;
 }
 
+int64_t irbfn_cluster_gate_vjp_workspace_bytes(int D, int R) {
+  if (D < 1 || R < 1) return IRBFN_ERR_BAD_ARG;
+  return cluster_gate_vjp_workspace_bytes(D, R);
+}
+
 int irbfn_cluster_gate_vjp(const float* x_dev, const float* gamma_dev, const float* dgamma_dev, const float* glogits_dev,
-                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R, void* stream) {
+                           float* dlogits_dev, float* g_wc_dev, float* g_bc_dev, int64_t B, int D, int R,
+                           void* workspace_dev, int64_t workspace_bytes, void* stream) {
   if (B < 0 || D < 1 || R < 1 || !g_wc_dev || !g_bc_dev) return IRBFN_ERR_BAD_ARG;
   if (B > 0 && (!x_dev || !gamma_dev || !dgamma_dev || !dlogits_dev)) return IRBFN_ERR_BAD_ARG;
+  if (B > 0 && (!workspace_dev || workspace_bytes < cluster_gate_vjp_workspace_bytes(D, R))) return IRBFN_ERR_BAD_ARG;
   return launch_cluster_gate_vjp(x_dev, gamma_dev, dgamma_dev, glogits_dev, dlogits_dev, g_wc_dev, g_bc_dev, B, D, R,
-                                 as_stream(stream));
+                                 static_cast<float*>(workspace_dev), as_stream(stream));
 }
 
 int irbfn_softmax_xent(const float* logits_dev, const float* labels_dev, float* glogits_dev, float* loss_dev,

@@ -125,8 +125,9 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
                float* g_kernel, float* g_bias, int64_t B, void* ws, int64_t ws_bytes, hipStream_t s,
                const float* gamma_ext = nullptr);
 int launch_dgamma(irbfn_net* net, const float* x, const float* gout, float* dgamma, int64_t B, hipStream_t s);
+int64_t cluster_gate_vjp_workspace_bytes(int D, int R);
 int launch_cluster_gate_vjp(const float* x, const float* gamma, const float* dgamma, const float* glogits, float* dlogits,
-                            float* g_wc, float* g_bc, int64_t B, int D, int R, hipStream_t s);
+                            float* g_wc, float* g_bc, int64_t B, int D, int R, float* ws, hipStream_t s);
 int launch_softmax_xent(const float* logits, const float* labels, float* glogits, float* loss, float* partials, int accumulate,
                         int64_t B, int R, hipStream_t s);
 int launch_rollout_forward(int mode, const float* x0u, const DynParams& dp, float* states, int64_t B,

@@ -398,6 +398,7 @@ class ClusterWCRBFNet:
     def __init__(self, in_features, out_features, num_kernels, basis_func, num_regions, **_unused):
         self.in_features, self.out_features = int(in_features), int(out_features)
         self.num_regions = int(num_regions)
+        self._gate_ws = {}
         # descriptor with R regions and no gate tables: the region weights come from the softmax gate
         self.stage = WCRBFNet(in_features=in_features, out_features=out_features, num_kernels=num_kernels,
                               basis_func=basis_func, num_regions=num_regions, lower_bounds=[], upper_bounds=[],
@@ -473,8 +474,14 @@ class ClusterWCRBFNet:
         st = lib.irbfn_net_vjp_gamma(h, _ptr(xd), _ptr(gamma), _ptr(gd), _ptr(leaves["centers"]), _ptr(leaves["log_sigs"]),
                                      _ptr(leaves["kernel"]), _ptr(leaves["bias"]), _ptr(dgamma), B, _ptr(ws), nbytes, stream)
         _lib.check(st, "irbfn_net_vjp_gamma")
+        gbytes = int(lib.irbfn_cluster_gate_vjp_workspace_bytes(D, R))
+        gws = self._gate_ws.get(dev.index)
+        if gws is None or gws.numel() < gbytes:
+            gws = torch.empty((max(gbytes, 4),), dtype=torch.uint8, device=dev)
+            self._gate_ws[dev.index] = gws
         st = lib.irbfn_cluster_gate_vjp(_ptr(xd), _ptr(gamma), _ptr(dgamma), _ptr(gl_in) if gl_in is not None else None,
-                                        _ptr(logits), _ptr(leaves["ckernel"]), _ptr(leaves["cbias"]), B, D, R, stream)
+                                        _ptr(logits), _ptr(leaves["ckernel"]), _ptr(leaves["cbias"]), B, D, R, _ptr(gws), gbytes,
+                                        stream)
         _lib.check(st, "irbfn_cluster_gate_vjp")
         conv = (lambda t: t) if out is not None else (lambda t: like_input(t, x, torch))
         return {"params": {"rbf_list": {"centers": conv(leaves["centers"]), "log_sigs": conv(leaves["log_sigs"])},
