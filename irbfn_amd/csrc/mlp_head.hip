@@ -196,10 +196,25 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_mfma_kernel(const float* __r
   float* Hs = W3s + 64 * GP + wave * WS;         // [TR][P]  raw h1 rows of the tile
   float* Dz = Hs + TR * P;                       // [TR][P]  d z2 with the batch on the rows
   float* Gs = Dz + TR * P;                       // [TR][GP] g rows, o padded to 16 with zeros
-  for (int i = tid; i < 64 * 64; i += 256) W2s[(i >> 6) * P + (i & 63)] = W2[i];
-  for (int i = tid; i < 64 * 16; i += 256) {
-    const int j = i >> 4, o = i & 15;
-    W3s[j * GP + o] = o < O ? W3[j * O + o] : 0.0f;
+  {                                              // block-shared copies of the weights (loads first, then the LDS writes)
+    float wv[16], w3v[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = W2[tid + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k, j = i >> 4, o = i & 15;
+      w3v[k] = o < O ? W3[j * O + o] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + 256 * k;
+      W2s[(i >> 6) * P + (i & 63)] = wv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k;
+      W3s[(i >> 4) * GP + (i & 15)] = w3v[k];
+    }
   }
   __syncthreads();
   auto wave_sync = [&]() {
@@ -218,18 +233,32 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_mfma_kernel(const float* __r
 #pragma unroll
   for (int nj = 0; nj < 4; ++nj) b2n[nj] = b2[nj * 16 + n];
   const long ntiles = (B + TR - 1) / TR;
+  // a tile's h1 rows (8 x 16-byte loads per lane: row 4k + lane / 16, columns 4 (lane % 16) ..) and g rows, requested one
+  // tile ahead
+  hf4 hv[TR / 4];
+  float gv[TR / 4];
+  auto fetch = [&](long tile) {
+    const long b0 = tile * TR;
+#pragma unroll
+    for (int k = 0; k < TR / 4; ++k) {
+      const long row = b0 + 4 * k + (lane >> 4);
+      const bool ok = tile < ntiles && row < B;
+      hv[k] = ok ? *reinterpret_cast<const hf4*>(h1 + row * 64 + 4 * (lane & 15)) : hf4{0, 0, 0, 0};
+      gv[k] = (ok && (lane & 15) < O) ? gout[row * O + (lane & 15)] : 0.0f;
+    }
+  };
+  fetch((long)blockIdx.x * 4 + wave);
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     const long b0 = tile * TR;
     const long left = B - b0;
     const int nvalid = left < TR ? (int)left : TR;
-    for (int i = lane; i < TR * 64; i += 64) {
-      const int r = i >> 6, c = i & 63;
-      Hs[r * P + c] = r < nvalid ? h1[(b0 + r) * 64 + c] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < TR / 4; ++k) {
+      float* d = Hs + (4 * k + (lane >> 4)) * P + 4 * (lane & 15);
+      d[0] = hv[k].x; d[1] = hv[k].y; d[2] = hv[k].z; d[3] = hv[k].w;
+      Gs[(4 * k + (lane >> 4)) * GP + (lane & 15)] = gv[k];
     }
-    for (int i = lane; i < TR * 16; i += 64) {
-      const int r = i >> 4, c = i & 15;
-      Gs[r * GP + c] = (r < nvalid && c < O) ? gout[(b0 + r) * O + c] : 0.0f;
-    }
+    fetch(tile + (long)gridDim.x * 4);           // the next tile's rows travel while this one is computed
     wave_sync();
     // (1) z2 = relu(h1) W2 + b2: D tile (mb, nj) = rows b = 16 mb + 4 g + r, column j = 16 nj + n
     hf4 z2[MB][4];
@@ -368,6 +397,122 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_mfma_kernel(const float* __r
   }
 }
 
+// ---- forward head on the f32 matrix cores (the default): out = relu(relu(h1) W2 + b2) W3 + b3, 32-row tiles per wave,
+// relu(z2) turned from D layout into A layout through the wave's LDS tile (mlp_head_kernel above: one lane per row, 52 us
+// at 80000 rows; this one 12 us)
+template <int H1, int H2>
+__global__ __launch_bounds__(256) void mlp_head_fwd_mfma_kernel(const float* __restrict__ h1, const float* __restrict__ W2,
+                                                                const float* __restrict__ b2, const float* __restrict__ W3,
+                                                                const float* __restrict__ b3, float* __restrict__ out, long B, int O) {
+  static_assert(H1 == 64 && H2 == 64, "the reference hard-codes Dense(64), Dense(64)");
+  extern __shared__ float lds[];
+  constexpr int P = kHeadP, GP = kHeadGP, TR = kHeadTR, MB = TR / 16;
+  float* W2s = lds;                              // [64][P]
+  float* W3s = W2s + 64 * P;                     // [64][GP]  W3[j][o], o padded to 16 with zeros
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  float* Hs = W3s + 64 * GP + wave * (TR * P);   // [TR][P]: relu(h1) rows, then relu(z2) rows
+  {                                              // block-shared copies of the weights (loads first, then the LDS writes)
+    float wv[16], w3v[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = W2[tid + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k, j = i >> 4, o = i & 15;
+      w3v[k] = o < O ? W3[j * O + o] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + 256 * k;
+      W2s[(i >> 6) * P + (i & 63)] = wv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k;
+      W3s[(i >> 4) * GP + (i & 15)] = w3v[k];
+    }
+  }
+  __syncthreads();
+  auto wave_sync = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  float b2n[4];
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj) b2n[nj] = b2[nj * 16 + n];
+  const float b3n = n < O ? b3[n] : 0.0f;
+  const long ntiles = (B + TR - 1) / TR;
+  // a tile's h1 rows: 8 x 16-byte loads per lane (row 4k + lane / 16, columns 4 (lane % 16) ..), requested one tile ahead
+  hf4 hv[TR / 4];
+  auto fetch = [&](long tile) {
+    const long b0 = tile * TR;
+#pragma unroll
+    for (int k = 0; k < TR / 4; ++k) {
+      const long row = b0 + 4 * k + (lane >> 4);
+      hv[k] = (tile < ntiles && row < B) ? *reinterpret_cast<const hf4*>(h1 + row * 64 + 4 * (lane & 15)) : hf4{0, 0, 0, 0};
+    }
+  };
+  fetch((long)blockIdx.x * 4 + wave);
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long b0 = tile * TR;
+    const long left = B - b0;
+    const int nvalid = left < TR ? (int)left : TR;
+#pragma unroll
+    for (int k = 0; k < TR / 4; ++k) {
+      float* d = Hs + (4 * k + (lane >> 4)) * P + 4 * (lane & 15);
+      d[0] = fmaxf(hv[k].x, 0.0f); d[1] = fmaxf(hv[k].y, 0.0f); d[2] = fmaxf(hv[k].z, 0.0f); d[3] = fmaxf(hv[k].w, 0.0f);   // nn.relu(out_pre1)
+    }
+    fetch(tile + (long)gridDim.x * 4);           // the next tile's rows travel while this one is computed
+    wave_sync();
+    hf4 z2[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) z2[mb][nj] = hf4{b2n[nj], b2n[nj], b2n[nj], b2n[nj]};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      float av[MB], bv[4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = Hs[(mb * 16 + n) * P + ks * 4 + g];
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) bv[nj] = W2s[(ks * 4 + g) * P + nj * 16 + n];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) z2[mb][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nj], z2[mb][nj], 0, 0, 0);
+    }
+    wave_sync();                                 // every read of relu(h1) is done: the tile takes relu(z2)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Hs[(mb * 16 + 4 * g + r) * P + nj * 16 + n] = fmaxf(z2[mb][nj][r], 0.0f);   // nn.relu(out_pre2)
+    wave_sync();
+    hf4 oacc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) oacc[mb] = hf4{b3n, b3n, b3n, b3n};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const float bv = W3s[(ks * 4 + g) * GP + n];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        oacc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Hs[(mb * 16 + n) * P + ks * 4 + g], bv, oacc[mb], 0, 0, 0);
+    }
+    if (n < O) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mb * 16 + 4 * g + r;
+          if (row < nvalid) out[(b0 + row) * O + n] = oacc[mb][r];
+        }
+    }
+    wave_sync();
+  }
+}
+
 // 64 consecutive values per block; thread (sg, v) sums slabs sg, sg + 4, ... in order, the four partial sums are added in
 // a fixed order: deterministic, coalesced, no single thread walks all the slabs
 __global__ __launch_bounds__(256) void mlp_head_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int n,
@@ -402,6 +547,18 @@ extern "C" int irbfn_mlp_head_forward(const float* h1_dev, const float* w2_dev, 
   if (!h1_dev || !w2_dev || !b2_dev || !w3_dev || !b3_dev || !out_dev) return IRBFN_ERR_BAD_ARG;
   if (H1 != 64 || H2 != 64) return IRBFN_ERR_UNSUPPORTED;      // the reference hard-codes Dense(64), Dense(64)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (O <= 16) {                                               // matrix-core head (every model card of the reference: O = 2 or 10)
+    const size_t lds = ((size_t)64 * kHeadP + 64 * kHeadGP + 4 * (size_t)kHeadTR * kHeadP) * sizeof(float);
+    auto k = mlp_head_fwd_mfma_kernel<64, 64>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }
+    const long tiles = (B + kHeadTR - 1) / kHeadTR;
+    const long blocks = (tiles + 3) / 4;
+    hipLaunchKernelGGL(k, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), lds, s, h1_dev, w2_dev, b2_dev, w3_dev,
+                       b3_dev, out_dev, (long)B, O);
+    IRBFN_HIP_CHECK(hipGetLastError());
+    return IRBFN_OK;
+  }
   const size_t lds = (size_t)kWave * (64 + 1) * sizeof(float);
   hipLaunchKernelGGL((mlp_head_kernel<64, 64>), dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds, s, h1_dev,
                      w2_dev, b2_dev, w3_dev, b3_dev, out_dev, (long)B, O);
