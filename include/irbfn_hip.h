@@ -257,7 +257,7 @@ int irbfn_lut_nearest(const float* inputs_dev, const float* table_dev, const flo
                       int64_t ws_bytes, void* stream);
 
 /* Way-point geometry of the planners' pure-pursuit front end, batched over B query points against ONE piecewise-linear
- * trajectory [N,2] (N <= 4096, float64 device arrays as the NumPy callers hold them):
+ * trajectory [N,2] (float64 device arrays as the NumPy callers hold them; one wave per point):
  * irbfn_nearest_point = nearest_point (src/irbfn_mpc/planner_utils.py:109-146): projection [B,2], distance, t in [0,1]
  *   and segment index of the closest point (first minimum, as np.argmin);
  * irbfn_intersect_point = intersect_point (:149-233): first point one `radius` away along the trajectory from

@@ -237,18 +237,21 @@ struct WayArgs {
   int N;
 };
 
+// One WAVE per point: the lanes take the segments lane, lane + 64, ... and the wave picks the smallest distance (the
+// smallest segment index among equal distances: np.argmin's first minimum).  (One thread per point walking all N
+// segments with a float64 divide and square root each took 200 us at ANY batch size -- the planner calls this with one
+// point per tick.)
 __global__ __launch_bounds__(256) void nearest_point_kernel(const WayArgs a, double* __restrict__ proj,
                                                             double* __restrict__ dist, double* __restrict__ tt,
                                                             int* __restrict__ seg) {
-  extern __shared__ double wp[];                 // [N][2]
-  for (int i = threadIdx.x; i < 2 * a.N; i += blockDim.x) wp[i] = a.traj[i];
-  __syncthreads();
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;                          // the whole wave
+  const double* __restrict__ wp = a.traj;
   const double px = a.pts[2 * b], py = a.pts[2 * b + 1];
   double best = INFINITY, bt = 0.0, bx = 0.0, by = 0.0;
-  int bi = 0;
-  for (int i = 0; i + 1 < a.N; ++i) {
+  int bi = 0x7fffffff;
+  for (int i = lane; i + 1 < a.N; i += 64) {
     const double x0 = wp[2 * i], y0 = wp[2 * i + 1];
     const float dx = (float)(wp[2 * i + 2] - x0), dy = (float)(wp[2 * i + 3] - y0);       // diffs.astype(float32) :125
     const float l2 = dx * dx + dy * dy;                                                  // :126
@@ -259,10 +262,22 @@ __global__ __launch_bounds__(256) void nearest_point_kernel(const WayArgs a, dou
     const double qx = x0 + t * (double)dx, qy = y0 + t * (double)dy;                     // :134
     const double ex = px - qx, ey = py - qy;
     const double d = sqrt(ex * ex + ey * ey);                                            // :137-138
-    if (d < best) { best = d; bt = t; bx = qx; by = qy; bi = i; }                        // np.argmin: first minimum
+    if (d < best) { best = d; bt = t; bx = qx; by = qy; bi = i; }                        // first minimum of this lane's segments
   }
-  proj[2 * b] = bx; proj[2 * b + 1] = by;
-  dist[b] = best; tt[b] = bt; seg[b] = bi;
+  double gbest = best;
+  int gbi = bi;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double od = __shfl_xor(gbest, off);
+    const int oi = __shfl_xor(gbi, off);
+    if (od < gbest || (od == gbest && oi < gbi)) { gbest = od; gbi = oi; }
+  }
+  if (gbi == 0x7fffffff) {                       // no segment compared below infinity (all NaN): the scalar loop's defaults
+    if (lane == 0) { proj[2 * b] = 0.0; proj[2 * b + 1] = 0.0; dist[b] = INFINITY; tt[b] = 0.0; seg[b] = 0; }
+  } else if (bi == gbi) {
+    proj[2 * b] = bx; proj[2 * b + 1] = by;
+    dist[b] = best; tt[b] = bt; seg[b] = bi;
+  }
 }
 
 __device__ __forceinline__ bool circle_hit(const double* wp, int N, int i, double px, double py, float radius,
@@ -295,30 +310,50 @@ __device__ __forceinline__ bool circle_hit(const double* wp, int N, int i, doubl
   return true;
 }
 
+// One wave per point: the search order of the reference (segments start_i .. N - 2, then, with wrap, -1 .. start_i - 1) is
+// walked 64 segments at a time; the first round with a hit ends the search and its lowest lane is the first intersection.
 __global__ __launch_bounds__(256) void intersect_point_kernel(const WayArgs a, const double* __restrict__ t0, float radius,
                                                               int wrap, float* __restrict__ first_p, int* __restrict__ first_i,
                                                               float* __restrict__ first_t, int* __restrict__ found) {
-  extern __shared__ double wp[];
-  for (int i = threadIdx.x; i < 2 * a.N; i += blockDim.x) wp[i] = a.traj[i];
-  __syncthreads();
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;                          // the whole wave
+  const double* __restrict__ wp = a.traj;
   const double px = a.pts[2 * b], py = a.pts[2 * b + 1];
   const double ts = t0 ? t0[b] : 0.0;
   const int start_i = (int)ts;                                                           // :155
   const float start_t = (float)fmod(ts, 1.0);                                            // :156
+  const int nfwd = a.N - 1 - start_i > 0 ? a.N - 1 - start_i : 0;                        // i = start_i .. N - 2
+  const int nwrap = wrap ? (start_i + 1 > 0 ? start_i + 1 : 0) : 0;                      // i = -1 .. start_i - 1   :205-231
   float t = NAN, qx = NAN, qy = NAN;                                                     // (None, None, None)
   int fi = 0, hit = 0;
-  for (int i = start_i; i + 1 < a.N && !hit; ++i)
-    if (circle_hit(wp, a.N, i, px, py, radius, i == start_i, start_t, t, qx, qy)) { fi = i; hit = 1; }
-  if (wrap && !hit)                                                                      // :205-231: i runs from -1
-    for (int i = -1; i < start_i && !hit; ++i)
-      if (circle_hit(wp, a.N, i, px, py, radius, false, 0.0f, t, qx, qy)) { fi = i; hit = 1; }
-  found[b] = hit;
-  first_i[b] = fi;
-  first_t[b] = t;
-  first_p[2 * b] = qx;
-  first_p[2 * b + 1] = qy;
+  for (int base = 0; base < nfwd + nwrap; base += 64) {
+    const int ord = base + lane;
+    bool h = false;
+    int i = 0;
+    if (ord < nfwd) {
+      i = start_i + ord;
+      h = circle_hit(wp, a.N, i, px, py, radius, ord == 0, start_t, t, qx, qy);
+    } else if (ord < nfwd + nwrap) {
+      i = ord - nfwd - 1;
+      h = circle_hit(wp, a.N, i, px, py, radius, false, 0.0f, t, qx, qy);
+    }
+    const unsigned long long m = __ballot(h);
+    if (m != 0ull) {
+      const int src = __ffsll((long long)m) - 1;                                         // the first hit in search order
+      t = __shfl(t, src); qx = __shfl(qx, src); qy = __shfl(qy, src); fi = __shfl(i, src);
+      hit = 1;
+      break;
+    }
+    t = NAN; qx = NAN; qy = NAN;
+  }
+  if (lane == 0) {
+    found[b] = hit;
+    first_i[b] = fi;
+    first_t[b] = t;
+    first_p[2 * b] = qx;
+    first_p[2 * b + 1] = qy;
+  }
 }
 
 extern "C" {
@@ -408,10 +443,8 @@ int irbfn_nearest_point(const double* points_dev, const double* trajectory_dev, 
   if (B < 0 || N < 2) return IRBFN_ERR_BAD_ARG;
   if (B == 0) return IRBFN_OK;
   if (!points_dev || !trajectory_dev || !proj_dev || !dist_dev || !t_dev || !seg_dev) return IRBFN_ERR_BAD_ARG;
-  const size_t lds = (size_t)N * 2 * sizeof(double);
-  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;          // <= 4096 way-points
   WayArgs a{points_dev, trajectory_dev, (long)B, N};
-  hipLaunchKernelGGL(nearest_point_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(nearest_point_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      a, proj_dev, dist_dev, t_dev, seg_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
@@ -423,10 +456,8 @@ int irbfn_intersect_point(const double* points_dev, const double* trajectory_dev
   if (B < 0 || N < 2) return IRBFN_ERR_BAD_ARG;
   if (B == 0) return IRBFN_OK;
   if (!points_dev || !trajectory_dev || !first_p_dev || !first_i_dev || !first_t_dev || !found_dev) return IRBFN_ERR_BAD_ARG;
-  const size_t lds = (size_t)N * 2 * sizeof(double);
-  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
   WayArgs a{points_dev, trajectory_dev, (long)B, N};
-  hipLaunchKernelGGL(intersect_point_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(intersect_point_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      a, t_start_dev, radius, wrap, first_p_dev, first_i_dev, first_t_dev, found_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
