@@ -176,7 +176,7 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_fingerprint(names=("rbf_forward_f16.hip", "f16_split.h", "rbf_forward.h", "rbf_forward.hip")) -> str:
+def kernel_fingerprint(names=("rbf_forward_f16.hip", "rbf_forward_f16_wide.h", "f16_split.h", "rbf_forward.h", "rbf_forward.hip")) -> str:
     """Hash of the sources the headline kernel is built from: profiles/*_traffic.json is only trusted for the
     code it was measured on (tools/measure_traffic.py stamps it)."""
     h = hashlib.sha1()
