@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark of the IRBFN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks as a child process tree)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -25,6 +25,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,8 +49,46 @@ def parse():
     ap.add_argument("--config", type=int, default=2, help="BASELINE config index (2 = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--scaling-extras-only", action="store_true",
+                    help="extras: only the multi-GPU numbers (broadcast, cfg-4 strong, cfg-3 weak), also at N = 1")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_cmd(args, argv):
+    """``python bench.py --gpus N`` typed directly (no RANK in the environment) with N > 1: the command that starts the
+    N ranks -- one process per GPU under ``torch.distributed.run`` -- or None when this process is itself a rank (or
+    N = 1).  Pure function of (args, argv, environment) so that the CPU suite can check it."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv) -> None:
+    """Runs the ranks as a FRESH child process tree and exits with its return code.  Must be called before anything
+    touches the GPU (never exec after HIP is initialised; this parent never initialises it).  Rank 0's JSON line goes
+    straight to the inherited stdout."""
+    cmd = self_launch_cmd(args, argv)
+    if cmd is None:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, available_cores() // args.gpus)))
+    sys.stdout.flush()
+    r = subprocess.run(cmd, env=env, cwd=ROOT)
+    raise SystemExit(r.returncode)
+
+
+def _dist_on() -> bool:
+    import torch
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
 def dist_setup(n_gpus):
@@ -56,7 +96,13 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world} (RANK is set: this process was started as a rank of "
+                         f"another job size; start `python bench.py --gpus {n_gpus}` without RANK/WORLD_SIZE and it "
+                         f"launches its own ranks)")
+    # IRBFN_BENCH_FORCE_DIST=1 (rehearsal knob): keep a process group alive at world size 1 too, so that one rank on a
+    # one-GPU box executes the whole RCCL branch (init with device_id, broadcast, all-reduce, max-over-ranks, barrier)
+    if world > 1 or os.environ.get("IRBFN_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -64,6 +110,8 @@ def dist_setup(n_gpus):
         # IRBFN_DIST_BACKEND=gloo avoids RCCL's one-rank-per-device rule; the driver uses neither.
         dev = 0 if os.environ.get("IRBFN_BENCH_SAME_DEVICE") == "1" else local
         backend = os.environ.get("IRBFN_DIST_BACKEND", "nccl")
+        if dev >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local rank {local} has no GPU (this node shows {torch.cuda.device_count()})")
         torch.cuda.set_device(dev)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -72,22 +120,20 @@ def dist_setup(n_gpus):
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    if world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     return rank, world, local
 
 
 def _barrier(world):
     import torch
     torch.cuda.synchronize()
-    if world > 1:
+    if _dist_on():
         torch.distributed.barrier()
     torch.cuda.synchronize()
 
 
 def _max_over_ranks(v, world):
     import torch
-    if world == 1:
+    if not _dist_on():
         return v
     t = torch.tensor([v], dtype=torch.float64)
     if torch.distributed.get_backend() == "nccl":
@@ -116,6 +162,7 @@ def timed_region(fn, steps, warmup, world):
 
 def main():
     args = parse()
+    self_launch(args, sys.argv[1:])              # --gpus N > 1 typed directly: start the ranks, relay, exit
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (irbfn_amd has no CPU fallback)")
@@ -146,7 +193,7 @@ def main():
     extras = None
     if not args.no_extras and idx == 2:
         extras = scaling_extras(net, params, x, rank, world, configs, torch)
-        if world == 1:
+        if world == 1 and not args.scaling_extras_only:
             extras.update(single_gpu_extras(net, params, x, configs, torch))
             net.bind(params)
 
@@ -166,11 +213,13 @@ def main():
                        "global_batch": B * world, "basis": card["basis_func"], "parallelism": f"dp{world} (query shards)"},
             "pair_evals_per_s": value * N,
             "roofline": roofline, "cpu_baseline": cpu,
+            "process_group": ({"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
+                              if _dist_on() else None),
         }
         if extras:
             line["extras"] = extras
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if _dist_on():
         _barrier(world)
         torch.distributed.destroy_process_group()
 
@@ -205,13 +254,15 @@ def forward_roofline(launch, B, N, D, O, kern_s):
     valu_flops = B * N * (3 * D + 2)
     mfma_flops = 2.0 * B * N * 16 * 3
     return {
-        "bound": "mfma", "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "bound": "mfma", "bound_detail": "compute roof; VALU-issue bound in fact (see note)", "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
         "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
         "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
-        "note": "algorithmic f32 flops (SURVEY 8d: B*N*(3D+2+2O), transcendental count B*N) over the fp32 peak 157.3 "
-                "TFLOP/s (fp32 vector == dense f32-input MFMA peak).  The kernel is VALU/transcendental-issue bound "
-                "(2400 flop/B), not HBM-bound; `by_unit` prices the two pipes it runs on separately",
+        "note": "`bound` takes the contract's two values: 'mfma' here means the COMPUTE roof (as opposed to 'hbm'), priced as "
+                "SURVEY 8d prescribes: algorithmic f32 flops (B*N*(3D+2+2O), transcendental count B*N) over the fp32 peak "
+                "157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak).  Within that roof the kernel is VALU/"
+                "transcendental-ISSUE bound (2400 flop/B, ~21.5 VALU instructions per pair; the matrix cores are ~7 % busy), "
+                "not MFMA-throughput bound and not HBM-bound; `by_unit` prices the two pipes it runs on separately",
         "by_unit": {
             "valu_f32": {"flops": valu_flops, "tflops": valu_flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS,
                          "frac": valu_flops / kern_s / 1e12 / PEAK_FP32_TFLOPS,

@@ -171,8 +171,8 @@ int irbfn_rollout_forward(int mode, const float* x0u_dev, const float* dyn_param
  * Replaces JAX's transpose of the scans under value_and_grad (scripts/train_nmpc.py:275-276,
  * :356-374; scripts/train_nmpc_frenet.py:408-409; deprecated/train_newlut.py:194-199).
  * clip() passes gradient 1 strictly inside its bounds, 0 strictly outside and `clip_tie` (0, 0.5 or
- * 1) exactly on a bound.  ST_SELECT differentiates the selected branch only
- * (finite where JAX's select would give NaN). */
+ * 1) exactly on a bound.  ST_SELECT returns IRBFN_ERR_UNSUPPORTED: the reference never
+ * differentiates integrate_st_mult, and jax.grad through its lax.select is NaN at V = 0. */
 int irbfn_rollout_vjp(int mode, const float* x0u_dev, const float* dyn_params_host,
                       const float* gstates_dev, float* g_x0u_dev, int64_t B, int T, float clip_tie,
                       void* stream);
@@ -303,7 +303,7 @@ int irbfn_softmax_xent(const float* logits_dev, const float* labels_dev, float* 
  * deeper=True, src/irbfn_mpc/irbfn_planner.py:286-298):  out = linear(relu(linear_pre2(relu(h1)))) with
  * h1 = linear_pre1(rbf_out) [B,H1] produced by irbfn_net_forward on a descriptor whose Dense layer is
  * linear_pre1.  w2[H1,H2], b2[H2], w3[H2,O], b3[O] device pointers; H1 = H2 = 64 (hard-coded in the
- * reference).  Forward only. */
+ * reference).  The VJP of the head is irbfn_mlp_head_vjp below. */
 int irbfn_mlp_head_forward(const float* h1_dev, const float* w2_dev, const float* b2_dev, const float* w3_dev,
                            const float* b3_dev, float* out_dev, int64_t B, int H1, int H2, int O, void* stream);
 

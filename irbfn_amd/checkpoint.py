@@ -83,24 +83,31 @@ def restore_checkpoint(ckpt: str) -> Tuple[dict, int]:
     tree = load_flax_msgpack(path)
     p = tree["params"]["params"] if "params" in tree["params"] else tree["params"]
     if "rbf_list" not in p or "linear" not in p or "centers" not in p["rbf_list"]:
-        raise ValueError(f"{path} does not hold a WCRBFNet / DeeperWCRBFNet parameter tree (found {sorted(p)}): "
-                         "MLP / Cluster variants are out of scope")
+        raise ValueError(f"{path} does not hold a WCRBFNet / DeeperWCRBFNet / ClusterWCRBFNet parameter tree "
+                         f"(found {sorted(p)}): the MLP baseline is out of scope")
     params = {"params": {
         "rbf_list": {"centers": np.asarray(p["rbf_list"]["centers"]), "log_sigs": np.asarray(p["rbf_list"]["log_sigs"])}}}
-    # WCRBFNet holds `linear`; DeeperWCRBFNet adds `linear_pre1`, `linear_pre2` (model.py:254-256)
-    for name in ("linear_pre1", "linear_pre2", "linear"):
+    # WCRBFNet holds `linear`; DeeperWCRBFNet adds `linear_pre1`, `linear_pre2` (model.py:254-256); ClusterWCRBFNet
+    # adds the gate's Dense `cluster` (model.py:341-414)
+    for name in _DENSE_GROUPS:
         if name in p:
             params["params"][name] = {"kernel": np.asarray(p[name]["kernel"]), "bias": np.asarray(p[name]["bias"])}
     return params, int(tree.get("step", 0))
 
 
+_DENSE_GROUPS = ("linear_pre1", "linear_pre2", "linear", "cluster")
+
+
 def _host_tree(params: dict) -> dict:
     p = params["params"] if "params" in params else params
+    unknown = sorted(set(p) - {"rbf_list", *_DENSE_GROUPS})
+    if unknown:          # never drop a parameter group silently: a checkpoint that cannot be resumed is worse than none
+        raise ValueError(f"parameter groups {unknown} are not part of any supported model (rbf_list + {_DENSE_GROUPS})")
 
     def host(a):
         return np.asarray(a.detach().cpu() if hasattr(a, "detach") else a)
     inner = {"rbf_list": {"centers": host(p["rbf_list"]["centers"]), "log_sigs": host(p["rbf_list"]["log_sigs"])}}
-    for name in ("linear_pre1", "linear_pre2", "linear"):
+    for name in _DENSE_GROUPS:
         if name in p:
             inner[name] = {"kernel": host(p[name]["kernel"]), "bias": host(p[name]["bias"])}
     return inner

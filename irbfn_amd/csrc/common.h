@@ -11,6 +11,9 @@ namespace irbfn {
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kMaxSplit = 8;       // nsplit <= 8 (gate dims)
 constexpr int kMaxD = 8;
+// blocks (= partial sums) of every two-stage loss / norm reduction: the size of the caller's `partials` buffer
+// (irbfn_train_loss_partials) -- train_step.hip and the cross-entropy of the cluster gate (rbf_vjp.hip) share it
+constexpr int kRedBlocks = 256;
 
 // basis classes the hot loops are specialised on
 enum BasisClass : int { BC_GAUSS = 0, BC_IQ = 1, BC_IMQ = 2, BC_GENERIC = 3 };

@@ -35,14 +35,19 @@ struct VjpArgs {
 // d phi / d(d2) from phi and d2.  The fast classes need phi only; the generic class covers the bases that depend on
 // d = sqrt(d2) itself (flax_rbf.py:55-111): d phi / d(d2) = phi'(d) * (0.5 / d), evaluated literally so that a query ON a
 // centre (d = 0) gives what jax.grad gives there -- sqrt has no derivative at 0: inf, and inf * 0 = NaN.
+// `ls_term` is the factor of the log_sig sum, in the units of `dphi_dd2 * r2` (the caller multiplies the finished sums by
+// -2 / sigma^2): for the d-dependent bases it is phi'(d) * d / (2 s2), i.e. d log_sig = phi'(d) * (-d) -- the width does
+// NOT go through the sqrt in the reference (flax_rbf.py:280: sqrt(sum sq) / exp(log_sig)), so its gradient is finite (0)
+// for a query on a centre, where only the centre path is NaN.
 template <int BC>
-__device__ __forceinline__ float dphi_dd2(float phi, float d2, float gscale, int basis) {
-  if constexpr (BC == BC_GAUSS) return -gscale * phi;          // exp(-a d2)
-  else if constexpr (BC == BC_IQ) return -(phi * phi);         // 1/(1+d2)
-  else if constexpr (BC == BC_IMQ) return -0.5f * phi * phi * phi;   // (1+d2)^-1/2
+__device__ __forceinline__ float dphi_dd2(float phi, float d2, float r2, float s2, float gscale, int basis, float& ls_term) {
+  float t;
+  if constexpr (BC == BC_GAUSS) t = -gscale * phi;             // exp(-a d2)
+  else if constexpr (BC == BC_IQ) t = -(phi * phi);            // 1/(1+d2)
+  else if constexpr (BC == BC_IMQ) t = -0.5f * phi * phi * phi;      // (1+d2)^-1/2
   else {
-    if (basis == IRBFN_MULTIQUADRIC) return 0.5f / phi;        // sqrt(1+d2)
-    if (basis == IRBFN_QUADRATIC) return 1.0f;                 // d2
+    if (basis == IRBFN_MULTIQUADRIC) { t = 0.5f / phi; ls_term = t * r2; return t; }   // sqrt(1+d2)
+    if (basis == IRBFN_QUADRATIC) { ls_term = r2; return 1.0f; }                          // d2
     const float d = sqrtf(d2);
     float dp;                                                  // phi'(d)
     switch (basis) {
@@ -56,8 +61,11 @@ __device__ __forceinline__ float dphi_dd2(float phi, float d2, float gscale, int
         break;
       default: dp = 0.0f; break;
     }
+    ls_term = 0.5f * dp * d / s2;
     return dp * (0.5f / d);
   }
+  ls_term = t * r2;
+  return t;
 }
 
 // Pre-pass: one packed, zero-padded record per query so that the hot loop reads ONE contiguous scalar
@@ -188,8 +196,11 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
     const float hbar = hb0 + hb1;
     // the centre's own factor -2 / sigma^2 multiplies the finished sums, not every pair:
     // d log_sig += t * (-2 d2) = (-2 s2) * t * r2,   d centre += (-2 t s2) * diff = (-2 s2) * t * diff
-    const float t = hbar * gam * dphi_dd2<BC>(phi, d2, a.gscale, a.basis);
-    gls = __builtin_fmaf(t, r2, gls);
+    float lsf;
+    const float hg = hbar * gam;
+    const float t = hg * dphi_dd2<BC>(phi, d2, r2, s2, a.gscale, a.basis, lsf);
+    if constexpr (BC == BC_GAUSS || BC == BC_IQ || BC == BC_IMQ) gls = __builtin_fmaf(t, r2, gls);
+    else gls = __builtin_fmaf(hg, lsf, gls);
 #pragma unroll
     for (int j = 0; j < D; ++j) gc[j] = __builtin_fmaf(t, diff[j], gc[j]);
   }
@@ -612,9 +623,9 @@ __global__ __launch_bounds__(256) void xent_final_kernel(const float* __restrict
 
 int launch_softmax_xent(const float* logits, const float* labels, float* glogits, float* loss, float* partials, int accumulate,
                         int64_t B, int R, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_xent_kernel, dim3(256), dim3(256), 0, s, logits, labels, glogits, partials, (long)B, R);
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(kRedBlocks), dim3(256), 0, s, logits, labels, glogits, partials, (long)B, R);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, s, partials, 256, loss, accumulate);
+  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, s, partials, kRedBlocks, loss, accumulate);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -632,13 +643,15 @@ static int launch_vjp_bc(const VjpArgs& a, int bc, bool gated, dim3 grid, hipStr
   case BCV: {                                                                                             \
     if (gated) {                                                                                          \
       auto k = rbf_vjp_kernel<D, OP, BCV, true>;                                                          \
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (lds > 48 * 1024)                                                                                \
+        IRBFN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
       hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                  \
     } else {                                                                                              \
       auto k = rbf_vjp_kernel<D, OP, BCV, false>;                                                         \
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (lds > 48 * 1024)                                                                                \
+        IRBFN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
       hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                  \
     }                                                                                                     \
     break;                                                                                                \

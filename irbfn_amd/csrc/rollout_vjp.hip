@@ -551,8 +551,8 @@ int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const fl
 #define IRBFN_RV(KERN)                                                                                         \
   do {                                                                                                         \
     if (lds > 48 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                     \
+      IRBFN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),                                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
     hipLaunchKernelGGL(KERN, grid, block, lds, s, a);                                                          \
   } while (0)
   switch (mode) {

@@ -17,8 +17,6 @@
 
 namespace irbfn {
 
-constexpr int kRedBlocks = 256;
-
 __device__ __forceinline__ float clipgrad_t(float v, float lo, float hi, float tie) {
   return (v > lo && v < hi) ? 1.0f : ((v == lo || v == hi) ? tie : 0.0f);
 }

@@ -64,6 +64,8 @@ def flat_param_count(net) -> int:
 
 
 def is_dist() -> bool:
+    """True when a process group is alive.  A group of ONE rank still runs its collectives (cheap, and it lets a
+    one-GPU box execute the RCCL branch end to end); without a group nothing collective is called."""
     return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
@@ -71,7 +73,7 @@ def broadcast_params(net, params: Optional[dict], src: int = 0, device: Optional
     """Rank ``src`` passes the pytree (others may pass None); every rank gets float32 tensors on its
     device, views into one flat buffer.  ONE collective (broadcast); none if not distributed."""
     device = device or default_device()
-    if not is_dist() or torch.distributed.get_world_size() == 1:
+    if not is_dist():
         if params is None:
             raise ValueError("params required on a single rank")
         return unflatten_params(net, flatten_params(params_to_device(params, device)).clone())
@@ -101,7 +103,7 @@ def shard_range(B: int, rank: Optional[int] = None, world: Optional[int] = None)
 def allreduce_grads(net, grads: dict) -> dict:
     """Sum of the per-rank partial parameter gradients (each rank saw its own query shard):
     one all-reduce of the flat buffer.  Identity when not distributed."""
-    if not is_dist() or torch.distributed.get_world_size() == 1:
+    if not is_dist():
         return grads
     import torch.distributed as dist
     flat = flatten_params(grads).clone()
@@ -111,7 +113,7 @@ def allreduce_grads(net, grads: dict) -> dict:
 
 def gather_outputs(local: torch.Tensor, B: int) -> torch.Tensor:
     """Optional: assemble the sharded outputs [B_local, ...] into [B, ...] on every rank."""
-    if not is_dist() or torch.distributed.get_world_size() == 1:
+    if not is_dist():
         return local
     import torch.distributed as dist
     world = dist.get_world_size()

@@ -87,13 +87,21 @@ class ClusterTrainState(TrainState):
 
     @classmethod
     def create(cls, net: ClusterWCRBFNet, params: dict, lr: float = 1e-3, max_grad_norm: float = 1.0,
-               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> "ClusterTrainState":
+               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8, opt_state=None) -> "ClusterTrainState":
+        """opt_state: (mu pytree, nu pytree, count) with the six leaves, to resume (``checkpoint.restore_opt_state``)."""
         torch = _lib.require_gpu()
-        p = params["params"] if "params" in params else params
-        stage = distributed.flatten_params(distributed.params_to_device(p))
-        flat = torch.cat([stage, to_device_f32(p["cluster"]["kernel"], torch).reshape(-1),
-                          to_device_f32(p["cluster"]["bias"], torch).reshape(-1)]).clone()
-        return cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+
+        def flat6(tree):
+            p = tree["params"] if "params" in tree else tree
+            stage = distributed.flatten_params(distributed.params_to_device(p))
+            return torch.cat([stage, to_device_f32(p["cluster"]["kernel"], torch).reshape(-1),
+                              to_device_f32(p["cluster"]["bias"], torch).reshape(-1)]).clone()
+        st = cls(net, flat6(params), lr, max_grad_norm, b1, b2, eps)
+        if opt_state is not None:
+            st.m.copy_(flat6(opt_state[0]))
+            st.v.copy_(flat6(opt_state[1]))
+            st.step.fill_(int(opt_state[2]))
+        return st
 
     def opt_state(self):
         return self._views(self.m), self._views(self.v), int(self.step.item())

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_build", "libirbfn_oracle.so")
+# IRBFN_ORACLE_LIB: load another build of the same sources (the sanitizer build, `make -C oracle asan`)
+LIB = os.environ.get("IRBFN_ORACLE_LIB") or os.path.join(HERE, "_build", "libirbfn_oracle.so")
 BASIS_ENUM = {"gaussian": 0, "gaussian_wide": 1, "gaussian_wider": 2, "inverse_quadratic": 3, "linear": 4,
               "quadratic": 5, "multiquadric": 6, "inverse_multiquadric": 7, "spline": 8, "poisson_one": 9,
               "poisson_two": 10, "matern32": 11, "matern52": 12}

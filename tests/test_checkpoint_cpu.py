@@ -113,3 +113,28 @@ def test_reads_reference_deeper_checkpoint():
     for k in ("rbf_list", "linear_pre1", "linear_pre2", "linear"):
         for n in fix["params"][k]:
             np.testing.assert_array_equal(params["params"][k][n], fix["params"][k][n])
+
+
+def test_cluster_tree_roundtrip_keeps_the_gate_and_its_moments(tmp_path):
+    """ClusterWCRBFNet (model.py:341-414): the gate's Dense `cluster` and its Adam moments survive save -> restore
+    (they were dropped silently); an unknown parameter group is refused, not dropped."""
+    rng = np.random.default_rng(3)
+    R, K, D, O = 3, 8, 8, 10
+    P = {"params": {"rbf_list": {"centers": rng.normal(size=(R, K, D)).astype(np.float32), "log_sigs": rng.normal(size=(R, K)).astype(np.float32)},
+                    "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)},
+                    "cluster": {"kernel": rng.normal(size=(D, R)).astype(np.float32), "bias": rng.normal(size=(R,)).astype(np.float32)}}}
+    mu = {"params": {g: {n: v * 0.5 for n, v in d.items()} for g, d in P["params"].items()}}
+    nu = {"params": {g: {n: v * v for n, v in d.items()} for g, d in P["params"].items()}}
+    checkpoint.save_checkpoint(str(tmp_path), P, step=11, opt_state=(mu, nu, 11))
+    back, step = checkpoint.restore_checkpoint(str(tmp_path))
+    assert step == 11 and set(back["params"]) == {"rbf_list", "linear", "cluster"}
+    for g, d in P["params"].items():
+        for n, v in d.items():
+            np.testing.assert_array_equal(back["params"][g][n], v)
+    m2, n2, cnt = checkpoint.restore_opt_state(str(tmp_path))
+    assert cnt == 11
+    np.testing.assert_array_equal(m2["params"]["cluster"]["kernel"], mu["params"]["cluster"]["kernel"])
+    np.testing.assert_array_equal(n2["params"]["cluster"]["bias"], nu["params"]["cluster"]["bias"])
+    bad = {"params": dict(P["params"], mystery={"kernel": np.zeros((2, 2), np.float32), "bias": np.zeros(2, np.float32)})}
+    with pytest.raises(ValueError):
+        checkpoint.save_checkpoint(str(tmp_path), bad, step=12)

@@ -1,6 +1,9 @@
 """bench.py contract (one JSON line with roofline / cpu_baseline objects) and the N > 1 launch path, rehearsed on
 ONE GPU: two ranks share cuda:0 over gloo (IRBFN_BENCH_SAME_DEVICE / IRBFN_DIST_BACKEND are rehearsal knobs; the
-driver launches one rank per GPU over RCCL)."""
+driver launches one rank per GPU over RCCL), the DIRECT form ``python bench.py --gpus 2`` (bench.py starts its own
+ranks), and ONE rank over backend "nccl" (IRBFN_BENCH_FORCE_DIST keeps the group alive at world size 1) so that the
+RCCL branch -- init with device_id, broadcast, all-reduce, max-over-ranks on CUDA tensors, barrier, destroy -- has
+executed on the box."""
 import json
 import os
 import subprocess
@@ -38,11 +41,46 @@ def test_single_gpu_line(gpu):
     assert cb["parity_rel_err_vs_f64"] < 1e-5
 
 
-def test_two_ranks_share_the_gpu_over_gloo(gpu):
-    env = dict(os.environ, IRBFN_BENCH_SAME_DEVICE="1", IRBFN_DIST_BACKEND="gloo")
+def _rank_free_env(**kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env.update(kw)
+    return env
+
+
+def test_two_ranks_under_torchrun_share_the_gpu_over_gloo(gpu):
+    """The launcher form (what the task statement shows for N > 1), headline only."""
+    env = _rank_free_env(IRBFN_BENCH_SAME_DEVICE="1", IRBFN_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5",
-                        "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "2", "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["process_group"] == {"backend": "gloo", "world_size": 2} and j["value"] > 0
+
+
+def test_one_rank_over_rccl(gpu):
+    """backend="nccl" (= RCCL) end to end on one GPU: a process group of ONE rank; every collective of the N > 1 path
+    runs on CUDA tensors (parameter broadcast, max-over-ranks, barrier, the gradient all-reduce of the cfg-3 extra)."""
+    env = _rank_free_env(IRBFN_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1", "--steps", "5",
+                        "--warmup", "2", "--no-cpu-baseline", "--scaling-extras-only"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["process_group"] == {"backend": "nccl", "world_size": 1} and j["value"] > 0
+    ex = j["extras"]
+    assert ex["broadcast_params_cfg4"]["ms"] > 0 and ex["cfg3_fwd_vjp_allreduce_weak"]["evals_per_s"] > 0
+    assert ex["cfg4_plan_tick_strong"]["batch_per_gpu"] == 262144
+
+
+def test_direct_form_starts_its_own_ranks(gpu):
+    """``python bench.py --gpus 2 ...`` exactly as the driver types it (no RANK in the environment): bench.py starts
+    the two ranks as a child process tree before touching the GPU and relays rank 0's line and the return code."""
+    env = _rank_free_env(IRBFN_BENCH_SAME_DEVICE="1", IRBFN_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)                      # ONE line (rank 0); the CPU baseline is an N = 1 item
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"]
