@@ -126,9 +126,10 @@ typedef enum irbfn_fwd_kernel {
   IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; one region + fast basis + O <= 128: K1h; O > 16: K1m; otherwise K1 */
   IRBFN_FWD_K1 = 1,   /* rbf_fwd_qlane: all-float32 VALU kernel (any net) */
   IRBFN_FWD_K1M = 2,  /* rbf_fwd_mfma: Phi x W on the f32-input matrix cores */
-  IRBFN_FWD_K1H = 3   /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
+  IRBFN_FWD_K1H = 3,  /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
+  IRBFN_FWD_K1R = 4   /* rbf_fwd_sparse: several regions, every query visits only the regions whose gamma != 0 */
 } irbfn_fwd_kernel;
-typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2 } irbfn_vjp_kernel;
+typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3 } irbfn_vjp_kernel;
 /* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
 int irbfn_net_set_option(irbfn_net* net, int option, int value);
 int irbfn_net_get_option(const irbfn_net* net, int option, int* value_out);

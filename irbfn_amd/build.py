@@ -34,6 +34,8 @@ UNITS = [
     ("rbf_forward_mfma.hip", "rbf_fwd_mfma.o", []),
     ("rbf_forward_f16.hip", "rbf_fwd_f16.o", []),
     ("rbf_forward_small.hip", "rbf_fwd_small.o", []),
+    # region-sparse kernels of the multi-region nets (per-lane lists of active regions)
+    ("rbf_sparse.hip", "rbf_sparse.o", ["-fno-slp-vectorize"]),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace

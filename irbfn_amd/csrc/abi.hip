@@ -108,6 +108,13 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
     irbfn_net_destroy(net);
     return IRBFN_ERR_HIP;
   }
+  if (nsplit > 0 && n_ranges > 0) {
+    const int rcs = sparse_setup(net, lo_tab_host, hi_tab_host, delta_host, dim_ranges_host);
+    if (rcs != IRBFN_OK) {
+      irbfn_net_destroy(net);
+      return rcs;
+    }
+  }
   *out_net = net;
   return IRBFN_OK;
 }
@@ -117,6 +124,7 @@ int irbfn_net_destroy(irbfn_net* net) {
   void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  sparse_free(net);
   delete net;
   return IRBFN_OK;
 }
@@ -127,6 +135,7 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
   int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->recm) rc = launch_pack_mfma(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->f16_img) rc = launch_pack_f16(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
+  if (rc == IRBFN_OK && net->sp_ok) rc = launch_pack_sparse(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
 }
@@ -134,8 +143,8 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
 int irbfn_net_set_option(irbfn_net* net, int option, int value) {
   if (!net || option < 0 || option >= IRBFN_OPT_COUNT || value < 0) return IRBFN_ERR_BAD_ARG;
   switch (option) {
-    case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1H) return IRBFN_ERR_BAD_ARG; break;
-    case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2H) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1R) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2R) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_SMALL: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 2 && value != 3) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_Q: if (value > 2) return IRBFN_ERR_BAD_ARG; break;

@@ -81,6 +81,11 @@ struct irbfn_net {
   float* gate_delta;
   int* gate_ranges;
   int nsplit, max_ranges, n_ranges;
+  // region-sparse path (rbf_sparse.hip): tables of the card, built by irbfn_net_create where the net is eligible
+  float* sp_img;            // the net as the region-sparse kernels hold it in LDS (rbf_sparse.hip, sp_img_layout): centre
+                            // table [n_ranges][RS], region index words, region masks, factor entries, Dense weight rows
+  int sp_ok, sp_E, sp_cap, sp_RS, sp_EW, sp_OPS;
+  float sp_mean_active;     // expected number of regions with gamma != 0 for a query uniform over the card's bounds
   bool has_params;
   int opt[IRBFN_OPT_COUNT];     // irbfn_net_set_option
   char last_name[96];
@@ -145,6 +150,13 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
                            const DynParams& dp, float* controls, float* states, int64_t B, int T,
                            hipStream_t s);
 int padded_O(int O);
+// region-sparse evaluation of multi-region nets (rbf_sparse.hip)
+int sparse_setup(irbfn_net* net, const float* lo, const float* hi, const float* delta, const int* dim_ranges);
+void sparse_free(irbfn_net* net);
+bool sparse_preferred(const irbfn_net* net, int64_t B);
+int launch_pack_sparse(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
+int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B, const int* mirror, int sv0, int mode,
+                          const float* state0, const DynParams* dp, float* states, int T, hipStream_t s);
 int rollout_state_dim(int mode);
 int rollout_input_dim(int mode, int T);
 }  // namespace irbfn

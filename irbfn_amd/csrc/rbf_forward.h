@@ -122,9 +122,17 @@ __device__ __forceinline__ void trans_block(float (&v)[NT]) {
 // one factor of the smooth indicator: ((tanh(delta*(x-lo))+1)/2) * ((tanh(delta*(hi-x))+1)/2), model.py:83-85.
 // (tanh(z)+1)/2 == 1/(1+exp(-2z)): evaluated in that form with v_exp_f32 / v_rcp_f32 (6 instructions instead of
 // ocml's ~35-instruction tanhf; <= 3e-7 relative, and without the float32 cancellation of tanh(z)+1 near z << 0).
-// Saturates to exactly 0 / 1 and propagates NaN like the tanh form.
+// FLOAT32 SEMANTICS OF THE ZERO: the reference evaluates this expression in float32 (its default), where tanh(z) IS -1
+// -- and the factor exactly 0 -- for every z below -13 ln 2 = -9.0109 (a correctly rounded float32 tanh rounds to -1 once
+// 2 e^{2z} < 2^-25).  The exp form alone would return 1.5e-8 ... 1e-38 there; it is flushed to the reference's exact 0
+// so that "gamma == 0" means the same in every kernel: a region whose gamma is 0 contributes exactly nothing, which is
+// what the region-sparse kernels (rbf_sparse.hip) skip.  A float64 run of the reference (--use_float64) keeps factors
+// down to 3e-17 there: the dropped terms are below 1.5e-8 of a region's own output ("K1r").
+// Saturates to exactly 1 by itself (1 + 2^-26 rounds to 1) and propagates NaN like the tanh form.
+constexpr float kGateSatZ = 9.0109133f;                              // 13 ln 2
 __device__ __forceinline__ float half_tanh_plus_one(float z) {
-  return fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * z));      // 2*log2(e)
+  const float v = fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * z));      // 2*log2(e)
+  return z < -kGateSatZ ? 0.0f : v;                                    // NaN: comparison false -> v = NaN
 }
 __device__ __forceinline__ float gate_factor(float xv, float lo, float hi, float delta) {
   return half_tanh_plus_one(delta * (xv - lo)) * half_tanh_plus_one(delta * (hi - xv));

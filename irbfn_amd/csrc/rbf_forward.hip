@@ -346,6 +346,11 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
     const int rc = launch_forward_small(net, x, out, B, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   }
+  // K1r: several regions with a sparse gate -> every query visits only its non-zero regions (rbf_sparse.hip)
+  if (forced == IRBFN_FWD_K1R || (forced == IRBFN_FWD_AUTO && sparse_preferred(net, B))) {
+    const int rc = launch_forward_sparse(net, x, out, B, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED || forced == IRBFN_FWD_K1R) return rc;
+  }
   // a kernel that is "not eligible" answers IRBFN_ERR_UNSUPPORTED; every other status (a HIP launch failure
   // of the preferred kernel in particular) is returned, never papered over by the next kernel in line
   int rc = try_forward_f16(net, x, out, B, s);
@@ -385,6 +390,14 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
     rc = launch_tick_f16_narrow(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
+  {
+    // several regions, sparse gate: forward + sign flip + roll-out in one launch of the region-sparse kernel
+    const int forced = net->opt[IRBFN_OPT_FWD_KERNEL];
+    if (forced == IRBFN_FWD_K1R || (forced == IRBFN_FWD_AUTO && sparse_preferred(net, B))) {
+      const int rc = launch_forward_sparse(net, x, controls, B, mirror, T, mode, state0, &dp, states, T, s);
+      if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+    }
   }
   if (controls && tick_through_controls(net, B)) {
     // wide outputs, and narrow ones on K1h without a one-launch instance: forward into the caller's controls buffer,

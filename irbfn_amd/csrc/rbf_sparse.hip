@@ -1,0 +1,717 @@
+// K1r / K2r: REGION-SPARSE evaluation of multi-region nets (R > 1) for gfx950.
+//
+// The reference evaluates WCRBFNet densely: every query meets all R regions and the products with a zero region
+// weight are computed and thrown away (src/irbfn_mpc/model.py:187-193: gamma_rep * all_x over [B,R,K]).  The smooth
+// indicator gamma (model.py:42-95) is a product of tanh sigmoids that is EXACTLY 0 in float32 outside a margin of
+// 9.01 / delta around a region's box (rbf_forward.h, half_tanh_plus_one), so on the reference's own planners a query
+// has gamma != 0 in 4-6 of 128 (or 12) regions.  Skipping gamma == 0 changes no result (0 * phi, phi finite).
+//
+// K1's skip is per WAVE (a region is skipped when all 64 queries of a wave have gamma == 0), which never fires on a
+// batch in arrival order.  Here every LANE walks its own list of active regions:
+//   1. the net's centres {c[D], folded width} sit in LDS (whole net: 43 KB for 128 regions x 10 centres), the Dense
+//      weights are wave-uniform (k is; the region is not) and stream through the scalar cache;
+//   2. a lane evaluates the per-(dimension, range) factors of its query once (E <= 32 of them, LDS column), keeps
+//      "factor != 0" as a bit mask M, and a wave-uniform scan over the regions appends r to the lane's list when
+//      (M & req[r]) == req[r]  (req[r] = the factor bits region r multiplies);
+//   3. the (query, active region) pairs of a workgroup are numbered query-major (prefix sum of the list lengths) and
+//      dealt to the lanes round by round, one pair per lane and round: the list lengths are very uneven (mean 3.6,
+//      max 32 on the 128-region planner -- a corner of the gate grid) and a lane that walked its own list would hold
+//      its whole wave for the longest one (measured: 62 us at any batch size, the time of ONE 32-region query);
+//   4. a lane finds its pair's query by binary search in the prefix sums, reads the region, forms gamma (product of
+//      the region's factors in the order of the reference's loop, model.py:88-93 -- bit-identical to the dense
+//      kernels' gamma) and runs the K centres of that region: per-lane LDS reads of the centre, wave-uniform weight
+//      rows; the pair's partial output goes to an LDS tile and the query's own lane adds its pairs in region order.
+// Result per query = sum over its active regions in ascending region order of the per-region sums: deterministic,
+// independent of the batch it is part of and of which lane served which pair, and equal to the dense kernels up to
+// the order of the float32 sum (K1 splits the centres over waves).
+//
+// The list capacity is a HARD bound computed on the host from the card (max number of simultaneously non-zero
+// ranges per dimension, intervals widened by 1e-4), nets whose bound or tables do not fit are served by the dense K1.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rbf_forward.h"
+#include "rollout_step.h"
+
+namespace irbfn {
+
+constexpr int kSpNT = 256;              // lanes (= queries) per workgroup
+constexpr int kSpMaxE = 32;             // factor entries (bits of the activity mask)
+constexpr int kSpMaxCap = 96;           // list capacity per query
+constexpr int kSpMaxRegions = 1024;     // the scan is linear in the number of regions
+constexpr size_t kSpMaxLds = 150 * 1024;
+
+int sparse_ops(int O) { return O <= 2 ? 2 : (O <= 5 ? 5 : (O <= 10 ? 10 : (O <= 16 ? 16 : -1))); }
+
+static inline int sp_entry_width(int DC) { return (DC + 1 + 3) & ~3; }
+
+// The net as ONE device image, laid out as it sits in LDS (dwords): [ centre table | region index words | region masks |
+// factor entries | Dense weight rows ], padded to whole KiB so that it is copied by LDS-DMA pieces alone.
+struct SpImg {
+  int idx, req, ent, wtab, small, ctab, total;
+};
+constexpr int kSpWP = 16;               // floats per weight row (OP <= 16; 16-byte reads)
+constexpr int kSpPartPitch = 20;        // floats per pair of the partial-output tile: 16-byte rows, conflict-free for b128 reads
+__host__ __device__ inline SpImg sp_img_layout(int nr, int RS, int E, int K) {
+  SpImg m;
+  int o = 0;
+  m.idx = o;  o += nr * 2;
+  o = (o + 3) & ~3;
+  m.req = o;  o += (nr + 31) & ~31;                              // whole 32-region words (padding: masks nobody satisfies)
+  m.ent = o;  o += E * 4;
+  m.wtab = o; o += K * kSpWP;
+  m.small = (o + 255) & ~255;                                    // the small tables: whole KiB pieces, requested first
+  m.ctab = m.small;
+  m.total = m.small + ((nr * RS + 255) & ~255);
+  return m;
+}
+// LDS layout (dwords), shared by host and kernel: the image, then the per-lane columns
+struct SpLds {
+  int ftab, xs, part, hw, flat_r, flat_q, wsum, total;
+};
+__host__ __device__ inline SpLds sp_lds_layout(int img_total, int nr, int E, int cap, int wide) {
+  SpLds l;
+  int o = img_total;
+  l.ftab = o; o += E * kSpNT;
+  l.xs = o;   o += 9 * kSpNT;                                    // x tile, pitch D|1 <= 9
+  o = (o + 3) & ~3;
+  l.part = o; o += kSpPartPitch * kSpNT;                         // partial outputs of a round
+  l.hw = o;   o += ((nr + 31) >> 5) * kSpNT;                     // hit words: bit r of a query's column = gamma_r != 0
+  l.flat_r = o; o += (cap * kSpNT * (wide ? 2 : 1) + 3) / 4;     // region of pair i (query-major numbering)
+  l.flat_q = o; o += (cap * kSpNT + 3) / 4;                      // owner (query) of pair i
+  l.wsum = o; o += kSpNT / 64 + 1;
+  l.total = o;
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: tables of the card (once per descriptor)
+// ---------------------------------------------------------------------------------------------------------------
+int sparse_setup(irbfn_net* net, const float* lo, const float* hi, const float* delta, const int* dr) {
+  net->sp_ok = 0;
+  const int ns = net->nsplit, nr = net->n_ranges, mr = net->max_ranges;
+  if (net->R < 2 || nr < 2 || ns < 1 || ns > kMaxSplit || nr > kSpMaxRegions) return IRBFN_OK;
+  const int OPS = sparse_ops(net->O);
+  if (OPS < 0) return IRBFN_OK;
+  // compact factor entries: one per (dimension, range index that some region uses)
+  std::vector<int> entry_of((size_t)ns * mr, -1);
+  std::vector<float> ent;                 // [E][4] = lo, hi, delta, (float)d
+  int E = 0;
+  double cap = 1.0, mean = 1.0;
+  for (int d = 0; d < ns; ++d) {
+    if (!(delta[d] > 0.0f) || !std::isfinite(delta[d])) return IRBFN_OK;     // the margin below needs delta > 0
+    std::vector<int> used;
+    for (int r = 0; r < nr; ++r) used.push_back(dr[r * ns + d]);
+    std::sort(used.begin(), used.end());
+    used.erase(std::unique(used.begin(), used.end()), used.end());
+    // non-zero interval of a range: (lo - Z/delta, hi + Z/delta), widened by 1e-4 (float32 rounding of delta*(x-lo))
+    const double marg = (double)kGateSatZ / delta[d] * (1.0 + 1e-4);
+    std::vector<std::pair<double, int>> ev;
+    double L = 1e300, U = -1e300, covered = 0.0;
+    for (int j : used) {
+      const double a = lo[d * mr + j], b = hi[d * mr + j];
+      if (!std::isfinite(a) || !std::isfinite(b)) return IRBFN_OK;
+      entry_of[(size_t)d * mr + j] = E++;
+      ent.insert(ent.end(), {(float)a, (float)b, delta[d], (float)d});
+      const double tiny = 1e-6 * (fabs(a) + fabs(b) + 1.0);
+      ev.push_back({a - marg - tiny, +1});
+      ev.push_back({b + marg + tiny, -1});
+      L = std::min(L, a); U = std::max(U, b);
+    }
+    std::sort(ev.begin(), ev.end(), [](const std::pair<double, int>& p, const std::pair<double, int>& q) {
+      return p.first < q.first || (p.first == q.first && p.second > q.second);      // openings first: closed intervals
+    });
+    int cur = 0, best = 0;
+    for (auto& e : ev) { cur += e.second; best = std::max(best, cur); }
+    for (int j : used) {                    // expected number of non-zero ranges for x uniform over the dimension's span
+      const double a = std::max(L, lo[d * mr + j] - marg), b = std::min(U, hi[d * mr + j] + marg);
+      covered += std::max(0.0, b - a);
+    }
+    cap *= best;
+    mean *= (U > L) ? std::max(1.0, covered / (U - L)) : (double)used.size();
+  }
+  if (E > kSpMaxE) return IRBFN_OK;
+  cap = std::min(cap, (double)nr);
+  mean = std::min(mean, (double)nr);
+  if (cap > kSpMaxCap) return IRBFN_OK;
+  const int EW = sp_entry_width(net->DC);
+  int RS = net->K * EW;
+  if (((RS / 4) & 1) == 0) RS += 4;          // odd number of 16-byte slots per region: lanes on different regions spread over the banks
+  // LDS of the forward: centre table + region index words + per-lane columns (factors, list, x tile)
+  const SpImg im = sp_img_layout(nr, RS, E, net->K);
+  if ((size_t)sp_lds_layout(im.total, nr, E, (int)cap, nr > 256 ? 1 : 0).total * 4 > kSpMaxLds) return IRBFN_OK;
+
+  std::vector<unsigned> req(nr), idx((size_t)nr * 2, 0xFFFFFFFFu);
+  for (int r = 0; r < nr; ++r) {
+    unsigned m = 0;
+    for (int d = 0; d < ns; ++d) {
+      const int e = entry_of[(size_t)d * mr + dr[r * ns + d]];
+      m |= 1u << e;
+      unsigned& w = idx[(size_t)r * 2 + (d >> 2)];
+      w = (w & ~(0xFFu << (8 * (d & 3)))) | ((unsigned)e << (8 * (d & 3)));
+    }
+    req[r] = m;
+  }
+  std::vector<unsigned> img((size_t)im.total, 0u);
+  memcpy(img.data() + im.idx, idx.data(), idx.size() * sizeof(unsigned));
+  for (int i = 0; i < ((nr + 31) & ~31); ++i) img[im.req + i] = i < nr ? req[i] : 0xFFFFFFFFu;
+  memcpy(img.data() + im.ent, ent.data(), ent.size() * sizeof(float));
+  hipError_t e = hipMalloc((void**)&net->sp_img, (size_t)im.total * 4);
+  if (e == hipSuccess) e = hipMemcpy(net->sp_img, img.data(), (size_t)im.total * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }
+  net->sp_E = E; net->sp_cap = (int)cap; net->sp_RS = RS; net->sp_EW = EW; net->sp_OPS = OPS;
+  net->sp_mean_active = (float)mean;
+  net->sp_ok = 1;
+  return IRBFN_OK;
+}
+
+void sparse_free(irbfn_net* net) {
+  if (net->sp_img) (void)hipFree(net->sp_img);
+  net->sp_img = nullptr;
+  net->sp_ok = 0;
+}
+
+// would the automatic dispatch take the region-sparse kernels?  (expected share of non-zero regions, uniform queries)
+bool sparse_preferred(const irbfn_net* net, int64_t B) {
+  // measured (profiles/r03_sparse_*.txt): 128 regions x 10 centres, 3.6 non-zero regions per query: 24 us against 74 dense;
+  // 12 regions x 100 centres, 5.7 of 12 non-zero: 60 us against 48 dense (per-lane centre reads cost more than half the
+  // pairs save) -> only clearly sparse gates
+  return net->sp_ok && B > 64 && net->sp_mean_active <= 0.25f * (float)net->n_ranges;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pack (once per parameter upload): ctab[r][k] = { c[0..DC), folded width scale, 0.. }, wtab[k] = W[k, 0..OPS)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sparse_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
+                                                          const float* __restrict__ kernel, float* __restrict__ ctab,
+                                                          float* __restrict__ wtab, int nr, int K, int D, int DC, int EW, int RS,
+                                                          int O, int OPS, int bclass, float gscale) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < K * kSpWP) {
+    const int k = n / kSpWP, o = n - k * kSpWP;
+    wtab[n] = o < O ? kernel[(size_t)k * O + o] : 0.0f;
+  }
+  if (n < nr * (RS - K * EW)) {                 // the padding slot behind each region's K entries
+    const int pad = RS - K * EW, r = n / pad, j = n - r * pad;
+    ctab[(size_t)r * RS + K * EW + j] = 0.0f;
+  }
+  if (n >= nr * K) return;
+  const int r = n / K, k = n - r * K;
+  float* dst = ctab + (size_t)r * RS + (size_t)k * EW;
+  for (int j = 0; j < EW; ++j) dst[j] = (j < D) ? centers[(size_t)n * D + j] : 0.0f;
+  const float s2 = expf(-2.0f * log_sigs[n]);
+  dst[DC] = bclass == BC_GAUSS ? -gscale * 1.4426950408889634f * s2 : s2;      // as rec[DC] of the dense kernels
+}
+
+int launch_pack_sparse(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
+  if (!net->sp_ok) return IRBFN_OK;
+  const int nr = net->n_ranges;
+  int n = std::max(nr * net->K, net->K * kSpWP);
+  n = std::max(n, nr * (net->sp_RS - net->K * net->sp_EW));
+  const SpImg im = sp_img_layout(nr, net->sp_RS, net->sp_E, net->K);
+  hipLaunchKernelGGL(sparse_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centers, log_sigs, kernel, net->sp_img + im.ctab,
+                     net->sp_img + im.wtab, nr, net->K, net->D, net->DC, net->sp_EW, net->sp_RS, net->O, net->sp_OPS, net->bclass,
+                     gauss_scale(net->basis));
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1r
+// ---------------------------------------------------------------------------------------------------------------
+struct SpArgs {
+  const float* __restrict__ x;
+  float* __restrict__ out;
+  const float* __restrict__ bias;
+  const float* __restrict__ img;       // sp_img_layout
+  long B;
+  int Dreal, O, K, nr, E, ns, cap, RS, basis, wide_list;
+  const int* __restrict__ mirror;
+  int sv0;
+  // fused roll-out (ROLL)
+  const float* __restrict__ state0;
+  float* __restrict__ states;
+  int T, mode;
+  DynParams dp;
+};
+
+// Diagnosis build only (tools/build_variant.py ... -DIRBFN_SP_STAMPS): wave 0 of block 0 records s_memtime at the phase
+// boundaries into a device array of its own; no output depends on it and the regular build contains none of it.
+#ifdef IRBFN_SP_STAMPS
+__device__ unsigned long long g_sp_stamps[32];
+#define IRBFN_SP_STAMP(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sp_stamps[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IRBFN_SP_STAMP(n) do { } while (0)
+#endif
+
+template <int D, int OP, int BC, bool ROLL>
+__global__ __launch_bounds__(kSpNT) void rbf_fwd_sparse(const SpArgs a) {
+  extern __shared__ float lds[];
+  constexpr int NT = kSpNT;
+  constexpr int EW = (D + 1 + 3) & ~3;
+  constexpr int XP = D | 1;                      // odd pitch of the x tile
+  const SpImg IM = sp_img_layout(a.nr, a.RS, a.E, a.K);
+  const SpLds L = sp_lds_layout(IM.total, a.nr, a.E, a.cap, a.wide_list);
+  const float* ctab_s = lds + IM.ctab;
+  const unsigned* idx_s = reinterpret_cast<const unsigned*>(lds + IM.idx);
+  const unsigned* req_s = reinterpret_cast<const unsigned*>(lds + IM.req);
+  const float* ent_s = lds + IM.ent;
+  const float* wtab_s = lds + IM.wtab;
+  float* ftab = lds + L.ftab;
+  float* xs = lds + L.xs;
+  float* part = lds + L.part;
+  unsigned* hw_s = reinterpret_cast<unsigned*>(lds + L.hw);
+  unsigned char* flat_r8 = reinterpret_cast<unsigned char*>(lds + L.flat_r);
+  unsigned short* flat_r16 = reinterpret_cast<unsigned short*>(lds + L.flat_r);
+  unsigned char* flat_q = reinterpret_cast<unsigned char*>(lds + L.flat_q);
+  int* wsum = reinterpret_cast<int*>(lds + L.wsum);
+  static_assert(NT <= 256, "pair owners are stored as bytes");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  IRBFN_SP_STAMP(0);
+  const long row0 = (long)blockIdx.x * NT;
+  const long left = a.B - row0;
+  const int nvalid = left < NT ? (int)left : NT;
+  const int Dr = a.Dreal;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned char* gimg = reinterpret_cast<const unsigned char*>(a.img) + lane * 16;
+  unsigned char* limg = reinterpret_cast<unsigned char*>(lds);
+
+  // ---- phase A: the small tables of the net (region masks and index words, factor entries, weight rows: everything a lane
+  // later reads by a wave-uniform address is a broadcast LDS read, not a scalar load the wave would stall on) by LDS-DMA,
+  // and the block's query tile through registers
+  {
+    float xv[D];
+    const float* xsrc = a.x + row0 * Dr;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int i = tid + u * NT;
+      xv[u] = i < nvalid * Dr ? xsrc[i] : 0.0f;
+    }
+    for (int v = wave; v < IM.small / 256; v += NT / kWave)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int i = tid + u * NT;
+      if (i < nvalid * Dr) {
+        const int r = i / Dr, j = i - r * Dr;
+        xs[r * XP + j] = xv[u];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // ---- the centre table (43 KB on the 128-region planner: ~2 us at the LDS-DMA rate of one CU) is requested now and lands
+  // while the lanes evaluate their gates; nobody reads it before the barrier in front of the rounds
+  for (int v = IM.small / 256 + wave; v < IM.total / 256; v += NT / kWave)
+    __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
+
+  // ---- this lane's query: factors of every (dimension, range) entry, activity mask.  Groups of four: the four entry
+  // reads are in flight together (a store to the factor column may alias them for the compiler: one at a time, every
+  // entry cost a full LDS round trip)
+  IRBFN_SP_STAMP(1);
+  const int q0 = tid < nvalid ? tid : nvalid - 1;
+  unsigned M = 0;
+  for (int e0 = 0; e0 < a.E; e0 += 4) {
+    float4 en[4];
+    float xv[4], f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u < a.E ? e0 + u : a.E - 1;
+      en[u] = *reinterpret_cast<const float4*>(ent_s + e * 4);    // {lo, hi, delta, dimension}: broadcast read
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = xs[q0 * XP + (int)en[u].w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = gate_factor(xv[u], en[u].x, en[u].y, en[u].z);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u < a.E) {
+        ftab[(e0 + u) * NT + tid] = f[u];
+        M |= (f[u] != 0.0f ? 1u : 0u) << (e0 + u);               // NaN counts as non-zero: it must reach the output
+      }
+    }
+  }
+  // ---- scan: regions whose factors are all non-zero (model.py:88-93: gamma = product of the region's factors).  32 regions
+  // at a time become a bit word without a branch; the words stay in the lane's LDS column
+  IRBFN_SP_STAMP(2);
+  int cnt = 0;
+  const int nwords = (a.nr + 31) >> 5;
+  for (int w = 0; w < nwords; ++w) {
+    unsigned h = 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const uint4 rq = *reinterpret_cast<const uint4*>(req_s + w * 32 + v * 4);
+      h |= ((M & rq.x) == rq.x ? 1u : 0u) << (4 * v);
+      h |= ((M & rq.y) == rq.y ? 1u : 0u) << (4 * v + 1);
+      h |= ((M & rq.z) == rq.z ? 1u : 0u) << (4 * v + 2);
+      h |= ((M & rq.w) == rq.w ? 1u : 0u) << (4 * v + 3);
+    }
+    const int rem = a.nr - w * 32;               // the padding masks are all ones: only a query with E = 32 live factors meets them
+    if (rem < 32) h &= (1u << rem) - 1u;
+    if (tid >= nvalid) h = 0;
+    // the list capacity is a hard bound for finite queries; a query with NaN coordinates can exceed it -- its output is NaN
+    // after the first region already, the surplus bits are dropped
+    while (cnt + __builtin_popcount(h) > a.cap) h &= ~(0x80000000u >> __builtin_clz(h));
+    cnt += __builtin_popcount(h);
+    hw_s[w * NT + tid] = h;
+  }
+  // ---- number the block's (query, region) pairs query-major: exclusive prefix sum of the list lengths
+  IRBFN_SP_STAMP(3);
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  if (lane == kWave - 1) wsum[wave] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NT / kWave; ++w) {
+    const int v = wsum[w];
+    wbase += w < wave ? v : 0;
+    total += v;
+  }
+  const int my_base = wbase + incl - cnt;
+  // ---- the pairs as flat arrays: region and owner of pair i.  One pass over the set bits of the lane's hit words.
+  {
+    int p = my_base;
+    for (int w = 0; w < nwords; ++w) {
+      unsigned h = hw_s[w * NT + tid];
+      while (h != 0) {
+        const int r = w * 32 + __builtin_ctz(h);
+        h &= h - 1;
+        if (a.wide_list) flat_r16[p] = (unsigned short)r;
+        else flat_r8[p] = (unsigned char)r;
+        flat_q[p] = (unsigned char)tid;
+        ++p;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of the centre table have landed
+  __syncthreads();
+
+  // ---- rounds: one pair per lane; the query's own lane then adds its pairs of the round in region order
+  float acc[OP];                                 // this lane's OWN query (tid): running sum over its pairs
+#pragma unroll
+  for (int o = 0; o < OP; ++o) acc[o] = 0.0f;
+  constexpr int WV = (OP + 3) / 4;               // 16-byte reads per weight row / partial-output row
+  IRBFN_SP_STAMP(4);
+  for (int i0 = 0; i0 < total; i0 += NT) {
+    if (i0 == 0) IRBFN_SP_STAMP(5);
+    const int i = i0 + tid;
+    const bool act = i < total;
+    const int ii = act ? i : 0;
+    const int qq = flat_q[ii];
+    const int r = a.wide_list ? (int)flat_r16[ii] : (int)flat_r8[ii];
+    const uint2 iw = *reinterpret_cast<const uint2*>(idx_s + r * 2);
+    float xq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) xq[j] = j < Dr ? xs[qq * XP + j] : 0.0f;
+    float g = act ? 1.0f : 0.0f;                 // model.py:88-93, factors in dimension order like the dense kernels
+#pragma unroll
+    for (int d = 0; d < kMaxSplit; ++d) {
+      if (d < a.ns) {
+        const unsigned e = ((d < 4 ? iw.x : iw.y) >> (8 * (d & 3))) & 0xFFu;
+        g *= ftab[e * NT + qq];
+      }
+    }
+    float pacc[OP];
+#pragma unroll
+    for (int o = 0; o < OP; ++o) pacc[o] = 0.0f;
+    const float* cp = ctab_s + r * a.RS;
+    auto load2 = [&](int kk, float (&cv)[2][EW], float (&wv)[2][4 * WV]) {      // centres kk, kk + 1 and their weight rows
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4* c4 = reinterpret_cast<const float4*>(cp + (kk + u) * EW);
+#pragma unroll
+        for (int v = 0; v < EW / 4; ++v) {
+          const float4 t4 = c4[v];
+          cv[u][4 * v] = t4.x; cv[u][4 * v + 1] = t4.y; cv[u][4 * v + 2] = t4.z; cv[u][4 * v + 3] = t4.w;
+        }
+        const float4* w4 = reinterpret_cast<const float4*>(wtab_s + (kk + u) * kSpWP);
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+          const float4 t4 = w4[v];
+          wv[u][4 * v] = t4.x; wv[u][4 * v + 1] = t4.y; wv[u][4 * v + 2] = t4.z; wv[u][4 * v + 3] = t4.w;
+        }
+      }
+    };
+    auto dist2 = [&](const float* cv) {
+      float r2 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float dd = xq[j] - cv[j];
+        r2 = __builtin_fmaf(dd, dd, r2);
+      }
+      return r2;
+    };
+    if (i0 == 0) IRBFN_SP_STAMP(6);
+    int k = 0;
+    if constexpr (BC != BC_GENERIC) {
+      // two centres per step through two register sets: the next two (and their weight rows) are requested before the
+      // current two are used, no copies between the sets
+      auto step2 = [&](const float (&cv)[2][EW], const float (&wv)[2][4 * WV]) {
+        float tt[2] = {basis_arg<BC>(dist2(cv[0]), cv[0][D]), basis_arg<BC>(dist2(cv[1]), cv[1][D])};
+        trans_block<BC, 2>(tt);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float pg = tt[u] * g;
+#pragma unroll
+          for (int o = 0; o < OP; ++o) pacc[o] = __builtin_fmaf(pg, wv[u][o], pacc[o]);
+        }
+      };
+      if (a.K >= 2) {
+        float cA[2][EW], wA[2][4 * WV], cB[2][EW], wB[2][4 * WV];
+        load2(0, cA, wA);
+        for (; k + 4 <= a.K; k += 4) {
+          load2(k + 2, cB, wB);
+          step2(cA, wA);
+          load2(k + 4 <= a.K - 2 ? k + 4 : a.K - 2, cA, wA);     // the pair after next (at the end: any valid pair)
+          step2(cB, wB);
+        }
+        if (k + 2 <= a.K) {                      // cA holds centres k, k + 1 (k <= K - 2 here)
+          step2(cA, wA);
+          k += 2;
+        }
+      }
+    }
+    for (; k < a.K; ++k) {
+      float cv[EW];
+      const float4* c4 = reinterpret_cast<const float4*>(cp + k * EW);
+#pragma unroll
+      for (int v = 0; v < EW / 4; ++v) {
+        const float4 t4 = c4[v];
+        cv[4 * v] = t4.x; cv[4 * v + 1] = t4.y; cv[4 * v + 2] = t4.z; cv[4 * v + 3] = t4.w;
+      }
+      const float pg = basis_from_r2<BC>(dist2(cv), cv[D], a.basis) * g;
+#pragma unroll
+      for (int o = 0; o < OP; ++o) pacc[o] = __builtin_fmaf(pg, wtab_s[k * kSpWP + o], pacc[o]);
+    }
+    if (i0 == 0) IRBFN_SP_STAMP(7);
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+      float4 t4;
+      t4.x = pacc[4 * v];
+      t4.y = 4 * v + 1 < OP ? pacc[4 * v + 1] : 0.0f;
+      t4.z = 4 * v + 2 < OP ? pacc[4 * v + 2] : 0.0f;
+      t4.w = 4 * v + 3 < OP ? pacc[4 * v + 3] : 0.0f;
+      *reinterpret_cast<float4*>(part + tid * kSpPartPitch + 4 * v) = t4;
+    }
+    __syncthreads();
+    if (i0 == 0) IRBFN_SP_STAMP(8);
+    {                                            // owner lanes: pairs [my_base, my_base + cnt) that fell into this round,
+      int j0 = my_base > i0 ? my_base : i0;      // added in region order; four rows in flight per step
+      int j1 = my_base + cnt;
+      j1 = j1 < i0 + NT ? j1 : i0 + NT;
+      auto row = [&](int j, float (&pv)[4 * WV]) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+          const float4 t4 = *reinterpret_cast<const float4*>(part + (j - i0) * kSpPartPitch + 4 * v);
+          pv[4 * v] = t4.x; pv[4 * v + 1] = t4.y; pv[4 * v + 2] = t4.z; pv[4 * v + 3] = t4.w;
+        }
+      };
+      int j = j0;
+      for (; j + 4 <= j1; j += 4) {
+        float p0[4 * WV], p1[4 * WV], p2[4 * WV], p3[4 * WV];
+        row(j, p0); row(j + 1, p1); row(j + 2, p2); row(j + 3, p3);
+#pragma unroll
+        for (int o = 0; o < OP; ++o) acc[o] = (((acc[o] + p0[o]) + p1[o]) + p2[o]) + p3[o];
+      }
+      for (; j < j1; ++j) {
+        float p0[4 * WV];
+        row(j, p0);
+#pragma unroll
+        for (int o = 0; o < OP; ++o) acc[o] += p0[o];
+      }
+    }
+    __syncthreads();
+    if (i0 == 0) IRBFN_SP_STAMP(9);
+  }
+  IRBFN_SP_STAMP(10);
+  const int qq = tid;                            // from here on every lane finishes its own query
+  const int qrow = q0;
+
+  // ---- Dense bias, mirror flip, output tile (coalesced)
+  const long bq = row0 + qrow;
+  const bool flip = a.mirror != nullptr && a.mirror[bq] != 0;
+#pragma unroll
+  for (int o = 0; o < OP; ++o) {
+    if (o < a.O) {
+      float v = acc[o] + a.bias[o];
+      if (flip && o >= a.sv0) v = -v;
+      acc[o] = v;
+    }
+  }
+  if (a.out != nullptr && tid < nvalid) {        // 4 * O bytes per lane, consecutive lanes = consecutive rows
+    float* dst = a.out + bq * a.O;
+#pragma unroll
+    for (int o = 0; o < OP; ++o)
+      if (o < a.O) dst[o] = acc[o];
+  }
+  IRBFN_SP_STAMP(11);
+  if constexpr (ROLL) {
+    // batched IRBFNPlanner.plan (irbfn_planner.py:205-212): the lane that holds a query's controls integrates its
+    // trajectory; the T x S states of the block's rows -- one contiguous piece of HBM -- leave through an LDS tile
+    constexpr int TM = OP / 2;
+    const int T = a.T;
+    const int Sdim = (a.mode == IRBFN_ROLLOUT_FULLINT) ? 5 : (a.mode == IRBFN_ROLLOUT_FRENET_LS ? 8 : 7);
+    const int rowf = T * Sdim;                   // <= 64
+    __syncthreads();
+    float* stage = lds;                          // [NT][65] over the centre table and the columns (all dead)
+    float* o = stage + qq * 65;
+    if (a.mode == IRBFN_ROLLOUT_ST_SELECT || a.mode == IRBFN_ROLLOUT_ST_KS) {
+      float s[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) s[i] = a.state0[bq * 7 + i];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+          // controls: u = [a_0..a_{T-1}, sv_0..sv_{T-1}] (dynamics.py:98); T == O/2 <= TM, static register indices
+          float ua = 0.0f, us = 0.0f;
+#pragma unroll
+          for (int o2 = 0; o2 < OP; ++o2) { ua = (o2 == t) ? acc[o2] : ua; us = (o2 == T + t) ? acc[o2] : us; }
+          if (a.mode == IRBFN_ROLLOUT_ST_SELECT) st_step<true>(s, ua, us, a.dp);
+          else st_step<false>(s, ua, us, a.dp);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) o[t * 7 + i] = s[i];
+        }
+      }
+    } else if (a.mode == IRBFN_ROLLOUT_FRENET_LS) {
+      float s[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = a.state0[bq * 8 + i];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+          float ua = 0.0f, us = 0.0f;
+#pragma unroll
+          for (int o2 = 0; o2 < OP; ++o2) { ua = (o2 == t) ? acc[o2] : ua; us = (o2 == T + t) ? acc[o2] : us; }
+          frenet_step(s, ua, us, a.dp);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[t * 8 + i] = s[i];
+        }
+      }
+    } else {
+      float s[5] = {0.0f, 0.0f, 0.0f, clipf(a.state0[bq], 0.0f, 7.0f), 0.0f};       // train_nmpc.py:319
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+          float ua = 0.0f, us = 0.0f;
+#pragma unroll
+          for (int o2 = 0; o2 < OP; ++o2) { ua = (o2 == t) ? acc[o2] : ua; us = (o2 == T + t) ? acc[o2] : us; }
+          fullint_step(s, ua, us);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) o[t * 5 + i] = s[i];
+        }
+      }
+    }
+    __syncthreads();
+    float* gout = a.states + row0 * (long)rowf;
+    for (int i = tid; i < nvalid * rowf; i += NT) {
+      const int r = i / rowf, c = i - r * rowf;
+      gout[i] = stage[r * 65 + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int OP, int BC, bool ROLL>
+static int sp_launch_one(const SpArgs& a, size_t lds, hipStream_t s, int* grid_out) {
+  auto k = rbf_fwd_sparse<D, OP, BC, ROLL>;
+  // the attribute call is a slow host call (it made back-to-back launches host-bound at ~30 us each): once per
+  // instance and device is enough -- the largest size any card may ask for
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  IRBFN_HIP_CHECK(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    IRBFN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kSpMaxLds));
+    attr_dev = dev;
+  }
+  const long grid = (a.B + kSpNT - 1) / kSpNT;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kSpNT), lds, s, a);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  *grid_out = (int)grid;
+  return IRBFN_OK;
+}
+
+template <int D, int OP, bool ROLL>
+static int sp_launch_bc(const SpArgs& a, int bc, size_t lds, hipStream_t s, int* g) {
+  switch (bc) {
+    case BC_GAUSS: return sp_launch_one<D, OP, BC_GAUSS, ROLL>(a, lds, s, g);
+    case BC_IQ: return sp_launch_one<D, OP, BC_IQ, ROLL>(a, lds, s, g);
+    case BC_IMQ: return sp_launch_one<D, OP, BC_IMQ, ROLL>(a, lds, s, g);
+    default:
+      if constexpr (ROLL) return IRBFN_ERR_UNSUPPORTED;
+      else return sp_launch_one<D, OP, BC_GENERIC, false>(a, lds, s, g);
+  }
+}
+
+template <int D, bool ROLL>
+static int sp_launch_d(const SpArgs& a, int OPS, int bc, size_t lds, hipStream_t s, int* g) {
+  switch (OPS) {
+    case 2: return sp_launch_bc<D, 2, ROLL>(a, bc, lds, s, g);
+    case 5: if constexpr (ROLL) return IRBFN_ERR_UNSUPPORTED; else return sp_launch_bc<D, 5, false>(a, bc, lds, s, g);
+    case 10: return sp_launch_bc<D, 10, ROLL>(a, bc, lds, s, g);
+    case 16: return sp_launch_bc<D, 16, ROLL>(a, bc, lds, s, g);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+#ifdef IRBFN_SP_STAMPS
+extern "C" int irbfn_debug_sparse_stamps(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sp_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
+
+// forward (states == nullptr) or the one-launch planning tick (states != nullptr, O == 2T, T*S <= 64)
+int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B, const int* mirror, int sv0,
+                          int mode, const float* state0, const DynParams* dp, float* states, int T, hipStream_t s) {
+  if (!net->sp_ok) return IRBFN_ERR_UNSUPPORTED;
+  const bool roll = states != nullptr;
+  if (roll) {
+    if (net->bclass == BC_GENERIC || net->O != 2 * T || T * rollout_state_dim(mode) > 64) return IRBFN_ERR_UNSUPPORTED;
+    if (net->sp_OPS != 2 && net->sp_OPS != 10 && net->sp_OPS != 16) return IRBFN_ERR_UNSUPPORTED;
+    if (net->DC != 7 && net->DC != 8) return IRBFN_ERR_UNSUPPORTED;
+  }
+  SpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.out = out; a.bias = net->bias; a.img = net->sp_img;
+  a.B = (long)B; a.Dreal = net->D; a.O = net->O; a.K = net->K; a.nr = net->n_ranges; a.E = net->sp_E; a.ns = net->nsplit;
+  a.cap = net->sp_cap; a.RS = net->sp_RS; a.basis = net->basis; a.wide_list = net->n_ranges > 256 ? 1 : 0;
+  a.mirror = mirror; a.sv0 = sv0;
+  if (roll) { a.state0 = state0; a.states = states; a.T = T; a.mode = mode; a.dp = *dp; }
+  const SpLds L = sp_lds_layout(sp_img_layout(a.nr, a.RS, a.E, a.K).total, a.nr, a.E, a.cap, a.wide_list);
+  size_t lds = (size_t)L.total * 4;
+  if (roll) lds = std::max(lds, (size_t)kSpNT * 65 * 4);
+  if (lds > kSpMaxLds) return IRBFN_ERR_UNSUPPORTED;
+  int grid = 0, rc;
+  switch (net->DC) {
+    case 3: rc = roll ? IRBFN_ERR_UNSUPPORTED : sp_launch_d<3, false>(a, net->sp_OPS, net->bclass, lds, s, &grid); break;
+    case 4: rc = roll ? IRBFN_ERR_UNSUPPORTED : sp_launch_d<4, false>(a, net->sp_OPS, net->bclass, lds, s, &grid); break;
+    case 7: rc = roll ? sp_launch_d<7, true>(a, net->sp_OPS, net->bclass, lds, s, &grid)
+                      : sp_launch_d<7, false>(a, net->sp_OPS, net->bclass, lds, s, &grid); break;
+    case 8: rc = roll ? sp_launch_d<8, true>(a, net->sp_OPS, net->bclass, lds, s, &grid)
+                      : sp_launch_d<8, false>(a, net->sp_OPS, net->bclass, lds, s, &grid); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_sparse<D=%d,OP=%d,BC=%d,ROLL=%d>", net->DC, net->sp_OPS,
+             net->bclass, (int)roll);
+    net->last_grid = grid;
+    net->last_block = kSpNT;
+  }
+  return rc;
+}
+
+}  // namespace irbfn

@@ -1,0 +1,138 @@
+"""Region-sparse evaluation of the multi-region nets (rbf_sparse.hip, K1r / K2r) against the dense gated kernels and
+the float64 oracle.  The reference evaluates every region for every query (src/irbfn_mpc/model.py:187-193); a region
+whose gamma is exactly 0 in float32 contributes nothing, so visiting only the regions with gamma != 0 must reproduce
+the dense result up to the ORDER of the float32 sum.
+
+Bound used below for sparse vs dense: both are float32 sums of the same <= R*K products gamma*phi*W in a different
+order, |a - b| <= 2 n eps sum_k |h_k W_ko| with n eps = 1280 * 6e-8 -> 2e-6 * sum|h W| (+ 1e-7 * |ref| for the bias add).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_ckpt_fixture
+from irbfn_amd import _lib, configs, planner
+from irbfn_amd.model import WCRBFNet
+from oracle import irbfn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+RUNS = ["dnmpc_128regions", "dnmpc_12regions_frenet_l1_bigdata"]
+
+
+def _queries(cfg, B, seed=0, border=False):
+    """In-range queries; border=True puts every split coordinate ON (or within 0.02 of) a range boundary, so that gamma
+    is strictly between 0 and 1 in several regions at once."""
+    rng = np.random.default_rng(seed)
+    ns, D = len(cfg["activation_idx"]), cfg["in_features"]
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)])
+    hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    x = np.hstack([rng.uniform(lo, hi, size=(B, ns)), rng.normal(size=(B, D - ns)) * 0.1])
+    if border:
+        for d in range(ns):
+            edges = np.array(sorted(set(cfg["lower_bounds"][d]) | set(cfg["upper_bounds"][d])))
+            x[:, d] = edges[rng.integers(0, len(edges), B)] + rng.choice([0.0, 0.02, -0.02, 0.3 / cfg["delta"][d]], B)
+    return x.astype(np.float32)
+
+
+def _cancel(cfg, P, x):
+    _, h, gamma = orc.wcrbfnet_apply(cfg, orc.cast_params(P, np.float64), x.astype(np.float64), return_aux=True)
+    return np.abs(h) @ np.abs(np.asarray(P["params"]["linear"]["kernel"], np.float64)), gamma
+
+
+@pytest.mark.parametrize("run", RUNS)
+@pytest.mark.parametrize("B", [65, 511, 513, 3000])
+def test_sparse_forward_matches_dense_and_oracle(gpu, run, B):
+    cfg, P, *_ = load_ckpt_fixture(run)
+    for border in (False, True):
+        x = _queries(cfg, B, seed=B, border=border)
+        ref = orc.wcrbfnet_apply(cfg, orc.cast_params(P, np.float64), x.astype(np.float64))
+        cancel, gamma = _cancel(cfg, P, x)
+        if border:                                  # the case is what it claims: several regions strictly inside (0, 1)
+            assert (((gamma > 1e-3) & (gamma < 0.999)).sum(axis=1) >= 2).mean() > 0.25
+        net = WCRBFNet.from_config(cfg)
+        net.set_options(fwd_kernel=_lib.FWD_K1R)
+        sp = net.apply(P, x)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<")
+        net.set_options(fwd_kernel=_lib.FWD_K1)
+        dn = net.apply(P, x)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_qlane<")
+        assert (np.abs(sp - dn) <= 2e-6 * cancel + 1e-7 * np.abs(ref)).all(), (run, B, border, np.abs(sp - dn).max())
+        assert (np.abs(sp - ref) <= 1e-5 * np.abs(ref) + 3e-6 * cancel).all(), (run, B, border)
+        net.set_options(fwd_kernel=_lib.FWD_AUTO)   # automatic dispatch: sparse where the gate is clearly sparse (3.6 of 128
+        au = net.apply(P, x)                        # regions live per query), dense where half the regions are (5.7 of 12)
+        if run == "dnmpc_128regions":
+            assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<") and np.array_equal(au, sp)
+        else:
+            assert net.last_launch()["kernel"].startswith("rbf_fwd_qlane<") and np.array_equal(au, dn)
+
+
+def test_sparse_forward_is_independent_of_the_batch_around_a_query(gpu):
+    """A query's result does not depend on which lane served it or what else is in the batch: bit-identical when the
+    batch is permuted and when the query is evaluated with a different neighbourhood."""
+    cfg, P, *_ = load_ckpt_fixture("dnmpc_128regions")
+    x = _queries(cfg, 2000, seed=5)
+    net = WCRBFNet.from_config(cfg)
+    net.set_options(fwd_kernel=_lib.FWD_K1R)
+    a = net.apply(P, x)
+    perm = np.random.default_rng(1).permutation(len(x))
+    b = net.apply(P, x[perm])
+    assert np.array_equal(a[perm], b)
+    c = net.apply(P, x[:700])
+    assert np.array_equal(a[:700], c)
+
+
+def test_sparse_forward_nan_inf_and_short_dimension_ranges(gpu):
+    cfg, P, *_ = load_ckpt_fixture("dnmpc_128regions")
+    x = _queries(cfg, 300, seed=9)
+    x[3, 1] = np.nan
+    x[5, 0] = np.inf
+    x[7, 2] = -np.inf
+    x[9, :] = np.nan                                  # every factor NaN: more "active" regions than the list holds
+    for c in (cfg, dict(cfg, dimension_ranges=cfg["dimension_ranges"][:100])):      # App. B-2: 28 regions stay 0
+        with np.errstate(all="ignore"):
+            ref = orc.wcrbfnet_apply(c, orc.cast_params(P, np.float64), x.astype(np.float64))
+        net = WCRBFNet.from_config(c)
+        net.set_options(fwd_kernel=_lib.FWD_K1R)
+        sp = net.apply(P, x)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<")
+        assert np.isnan(sp[[3, 9]]).all() and np.isnan(ref[[3, 9]]).all()
+        ok = np.ones(len(x), bool); ok[[3, 9]] = False
+        assert np.isfinite(sp[ok]).all()
+        cancel, _ = _cancel(c, P, np.nan_to_num(x, nan=0.0, posinf=1e30, neginf=-1e30))
+        assert (np.abs(sp[ok] - ref[ok]) <= 1e-5 * np.abs(ref[ok]) + 3e-6 * cancel[ok]).all()
+        # x = +-inf: the gate closes every region (one factor is exactly 0) -> bias, as the oracle
+        assert np.allclose(sp[[5, 7]], ref[[5, 7]], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("run,mode", [("dnmpc_128regions", _lib.ROLLOUT_ST_SELECT), ("dnmpc_128regions", _lib.ROLLOUT_ST_KS),
+                                      ("dnmpc_128regions", _lib.ROLLOUT_FULLINT)])
+def test_sparse_tick_equals_forward_then_rollout(gpu, run, mode):
+    """irbfn_plan_tick on a multi-region planner net: forward + sign flip of the mirrored rows + 5-step roll-out in ONE
+    launch of the sparse kernel == sparse forward -> un-mirror -> stand-alone roll-out, bit for bit (shared step
+    functions), with and without mirror flags, ragged batch."""
+    import torch
+    from irbfn_amd import dynamics
+    cfg, P, *_ = load_ckpt_fixture(run)
+    net = WCRBFNet.from_config(cfg)
+    B = 1300
+    x = torch.from_numpy(_queries(cfg, B, seed=3)).cuda()
+    rng = np.random.default_rng(4)
+    if mode == _lib.ROLLOUT_FULLINT:
+        s0 = torch.from_numpy(rng.uniform(0, 7, size=(B, 1)).astype(np.float32)).cuda()
+    else:
+        s0 = torch.from_numpy(configs.initial_state_from_query(x.cpu().numpy())).cuda()
+    mirror = torch.from_numpy((rng.random(B) < 0.4).astype(np.int32)).cuda()
+    for m in (None, mirror):
+        net.set_options(fwd_kernel=_lib.FWD_K1R)
+        ctrl, states = planner.plan_tick(net, P, x, m, s0, configs.DYN_PARAMS, mode=mode)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<") and "ROLL=1" in net.last_launch()["kernel"]
+        u = net.apply(P, x).clone()
+        if m is not None:
+            u[m.bool(), 5:] *= -1.0
+        assert torch.equal(ctrl, u)
+        if mode == _lib.ROLLOUT_FULLINT:
+            ref_states = dynamics.rollout_fullint(s0.reshape(-1), u)
+        elif mode == _lib.ROLLOUT_ST_KS:
+            ref_states = dynamics.integrate_st_ks_mult(torch.cat([s0, u], dim=1), configs.DYN_PARAMS)
+        else:
+            ref_states = dynamics.integrate_st_mult(torch.cat([s0, u], dim=1), configs.DYN_PARAMS)
+        assert torch.equal(states, ref_states.reshape(states.shape))
