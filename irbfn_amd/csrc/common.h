@@ -155,6 +155,11 @@ int sparse_setup(irbfn_net* net, const float* lo, const float* hi, const float* 
 void sparse_free(irbfn_net* net);
 bool sparse_preferred(const irbfn_net* net, int64_t B);
 int launch_pack_sparse(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
+bool sparse_vjp_eligible(const irbfn_net* net);
+int sparse_vjp_slices(const irbfn_net* net, int64_t B);
+size_t sparse_vjp_workspace_bytes(const irbfn_net* net, int64_t B);
+int launch_vjp_sparse(irbfn_net* net, const float* x, const float* gout, int64_t B, void* spws, float* part, int SL, int Npad,
+                      hipStream_t s);
 int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B, const int* mirror, int sv0, int mode,
                           const float* state0, const DynParams* dp, float* states, int T, hipStream_t s);
 int rollout_state_dim(int mode);

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "rbf_forward.h"
+#include "rbf_vjp_f16.h"
 #include "rollout_step.h"
 
 namespace irbfn {
@@ -710,6 +711,500 @@ int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B,
              net->bclass, (int)roll);
     net->last_grid = grid;
     net->last_block = kSpNT;
+  }
+  return rc;
+}
+
+
+// ===============================================================================================================
+// K2r: region-sparse parameter VJP
+// ===============================================================================================================
+// The dense K2 streams EVERY query past every centre (lane = centre, 206 us for the 128-region planner at the
+// reference's batch of 80000, plus 30-60 us of query packing).  Here the (query, region) pairs with gamma != 0 -- 3.6 per
+// query -- are listed per REGION by a stable counting sort (no position comes from an atomic: the order of a region's list,
+// hence the order of every sum, is fixed by the batch order -> bitwise reproducible gradients):
+//   sparse_pairs_kernel<COUNT>  per wave of 64 queries: number of hits per region            -> wcnt[wave][region]
+//   sparse_scan_kernel          per region: exclusive prefix over the waves, region totals   -> offs[wave][region], tot[region]
+//   sparse_pairs_kernel<FILL>   same scan again: pair (query index, gamma) -> pairs[base[r] + offs[wave][r] + rank in wave]
+//   rbf_vjp_sparse              one wave per (region, slice of its list): lanes = pairs (P per lane in registers: x, cotangent
+//                               row, gamma), loop over the region's K centres (wave-uniform: scalar loads), per centre the D + 1
+//                               + O sums over the wave's pairs by a fixed butterfly, accumulated per slice in LDS -> slab
+//   vjp_reduce_kernel (+ regions)  the dense path's fixed-order slab reduce (rbf_vjp.hip)
+struct SpPairArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ img;
+  long B;
+  int Dreal, nr, E, ns, RS, K, cap, nwv;
+  int* __restrict__ wcnt;              // [nwv][nr]
+  const int* __restrict__ offs;        // [nwv][nr]  (FILL)
+  const int* __restrict__ tot;         // [nr]       (FILL)
+  int2* __restrict__ pairs;            // {query index, gamma bits}
+};
+
+// bit u of every lane's word -> ballot -> lane LB + u of (mlo, mhi).  v_writelane_b32 takes ONE scalar register (constant-bus
+// rule): the lane select is an inline constant, hence the compile-time recursion (this clang has no builtin for the instruction)
+template <int LB, int U>
+struct SpTranspose {
+  static __device__ __forceinline__ void run(unsigned h, unsigned& mlo, unsigned& mhi) {
+    const unsigned long long bal = __ballot((h >> U) & 1u);
+    // gfx940+: a VALU that reads an SGPR a VALU has just written (the ballot's v_cmp) needs 2 wait states.  hipcc inserts them
+    // for its own instructions, never inside inline asm: without the s_nop the lane received a STALE mask now and then
+    // (count and fill passes disagreed -> pairs read from unwritten slots -> memory fault on the second call).
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                 : "+v"(mlo), "+v"(mhi)
+                 : "s"((unsigned)bal), "s"((unsigned)(bal >> 32)), "n"(LB + U));
+    SpTranspose<LB, U + 1>::run(h, mlo, mhi);
+  }
+};
+template <int LB>
+struct SpTranspose<LB, 32> {
+  static __device__ __forceinline__ void run(unsigned, unsigned&, unsigned&) {}
+};
+
+template <int D, bool FILL>
+__global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a) {
+  extern __shared__ float lds[];
+  constexpr int NT = kSpNT;
+  constexpr int XP = D | 1;
+  const SpImg IM = sp_img_layout(a.nr, a.RS, a.E, a.K);
+  const unsigned* idx_s = reinterpret_cast<const unsigned*>(lds + IM.idx);
+  const unsigned* req_s = reinterpret_cast<const unsigned*>(lds + IM.req);
+  const float* ent_s = lds + IM.ent;
+  const int nwords = (a.nr + 31) >> 5;
+  const int nr64 = (a.nr + 63) & ~63;
+  float* ftab = lds + IM.small;                  // [E][NT]
+  float* xs = ftab + a.E * NT;                   // [NT][XP]
+  unsigned* hw_s = reinterpret_cast<unsigned*>(xs + 9 * NT);          // [nwords][NT] hit words of the lanes
+  uint2* masks_s = reinterpret_cast<uint2*>(hw_s + nwords * NT);      // FILL: [NT / 64][nr64] lanes of the wave that hit region r
+  int* base_s = reinterpret_cast<int*>(masks_s + (NT / kWave) * nr64);   // FILL: [nr] first pair of each region
+  int* woffs_s = base_s + a.nr;                  // FILL: [NT / 64][nr] this wave's offset inside each region's list
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * NT;
+  const long left = a.B - row0;
+  const int nvalid = left < NT ? (int)left : NT;
+  const int Dr = a.Dreal;
+  const long wv = (long)blockIdx.x * (NT / kWave) + wave;     // this wave's unit (64 consecutive queries)
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  {
+    float xv[D];
+    const float* xsrc = a.x + row0 * Dr;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int i = tid + u * NT;
+      xv[u] = i < nvalid * Dr ? xsrc[i] : 0.0f;
+    }
+    const unsigned char* gimg = reinterpret_cast<const unsigned char*>(a.img) + lane * 16;
+    unsigned char* limg = reinterpret_cast<unsigned char*>(lds);
+    for (int v = wave; v < IM.small / 256; v += NT / kWave)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
+    if constexpr (FILL) {
+      if (wv < a.nwv)
+        for (int r = lane; r < a.nr; r += kWave) woffs_s[wave * a.nr + r] = a.offs[wv * a.nr + r];
+      if (wave == 0) {                           // region bases: exclusive prefix of the totals, 64 regions per step
+        int run = 0;
+        for (int r0 = 0; r0 < a.nr; r0 += kWave) {
+          const int r = r0 + lane;
+          const int v = r < a.nr ? a.tot[r] : 0;
+          int incl = v;
+#pragma unroll
+          for (int off = 1; off < kWave; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+          }
+          if (r < a.nr) base_s[r] = run + incl - v;
+          run += __shfl(incl, kWave - 1);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int i = tid + u * NT;
+      if (i < nvalid * Dr) {
+        const int r = i / Dr, j = i - r * Dr;
+        xs[r * XP + j] = xv[u];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // factors + activity mask: the forward's code (rbf_fwd_sparse), same groups of four
+  const int q0 = tid < nvalid ? tid : nvalid - 1;
+  unsigned M = 0;
+  for (int e0 = 0; e0 < a.E; e0 += 4) {
+    float4 en[4];
+    float xv[4], f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u < a.E ? e0 + u : a.E - 1;
+      en[u] = *reinterpret_cast<const float4*>(ent_s + e * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = xs[q0 * XP + (int)en[u].w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = gate_factor(xv[u], en[u].x, en[u].y, en[u].z);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u < a.E) {
+        if constexpr (FILL) ftab[(e0 + u) * NT + tid] = f[u];
+        M |= (f[u] != 0.0f ? 1u : 0u) << (e0 + u);
+      }
+    }
+  }
+  // hit words (as the forward), and their TRANSPOSE: for every region the 64-bit mask of the wave's lanes that hit it.
+  // Bit u of a word -> one ballot -> lane (r mod 64) of a register pair: 5 instructions per region, no branch.  The mask
+  // gives the wave's count of a region (popcount) and a lane's rank in it (popcount below the lane): a stable order.
+  int cnt = 0;
+  unsigned mlo = 0, mhi = 0;
+  for (int w = 0; w < nwords; ++w) {
+    unsigned h = 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const uint4 rq = *reinterpret_cast<const uint4*>(req_s + w * 32 + v * 4);
+      h |= ((M & rq.x) == rq.x ? 1u : 0u) << (4 * v);
+      h |= ((M & rq.y) == rq.y ? 1u : 0u) << (4 * v + 1);
+      h |= ((M & rq.z) == rq.z ? 1u : 0u) << (4 * v + 2);
+      h |= ((M & rq.w) == rq.w ? 1u : 0u) << (4 * v + 3);
+    }
+    const int rem = a.nr - w * 32;
+    if (rem < 32) h &= (1u << rem) - 1u;
+    if (tid >= nvalid) h = 0;
+    while (cnt + __builtin_popcount(h) > a.cap) h &= ~(0x80000000u >> __builtin_clz(h));     // as the forward (NaN queries)
+    cnt += __builtin_popcount(h);
+    if constexpr (FILL) hw_s[w * NT + tid] = h;
+    if (w & 1) SpTranspose<32, 0>::run(h, mlo, mhi);
+    else SpTranspose<0, 0>::run(h, mlo, mhi);
+    if ((w & 1) == 1 || w == nwords - 1) {       // 64 regions done: lane l holds the mask of region (w / 2) * 64 + l
+      const int r = (w >> 1) * 64 + lane;
+      if constexpr (!FILL) {
+        if (wv < a.nwv && r < a.nr) a.wcnt[wv * a.nr + r] = __builtin_popcount(mlo) + __builtin_popcount(mhi);
+      } else {
+        masks_s[wave * nr64 + r] = make_uint2(mlo, mhi);
+      }
+      mlo = 0; mhi = 0;
+    }
+  }
+  if constexpr (FILL) {
+    // each lane walks its own hits: rank from the region's mask, gamma from the region's factors, position, store
+    for (int w = 0; w < nwords; ++w) {
+      unsigned h = hw_s[w * NT + tid];
+      while (h != 0) {
+        const int r = w * 32 + __builtin_ctz(h);
+        h &= h - 1;
+        const uint2 mk = masks_s[wave * nr64 + r];
+        const uint2 iw = *reinterpret_cast<const uint2*>(idx_s + r * 2);
+        const int pos0 = base_s[r] + woffs_s[wave * a.nr + r];
+        const int rank = __builtin_amdgcn_mbcnt_hi(mk.y, __builtin_amdgcn_mbcnt_lo(mk.x, 0u));
+        float g = 1.0f;                          // model.py:88-93, dimension order: the gamma of every other kernel, bit for bit
+#pragma unroll
+        for (int d = 0; d < kMaxSplit; ++d) {
+          if (d < a.ns) {
+            const unsigned e = ((d < 4 ? iw.x : iw.y) >> (8 * (d & 3))) & 0xFFu;
+            g *= ftab[e * NT + tid];
+          }
+        }
+        a.pairs[pos0 + rank] = make_int2((int)(row0 + tid), __float_as_int(g));
+      }
+    }
+  }
+}
+
+// per region: exclusive prefix of the per-wave counts (the order of a region's list = batch order), and the total
+__global__ __launch_bounds__(256) void sparse_scan_kernel(const int* __restrict__ wcnt, int* __restrict__ offs,
+                                                          int* __restrict__ tot, int nwv, int nr) {
+  __shared__ int sm[256];
+  const int r = blockIdx.x, t = threadIdx.x;
+  const int chunk = (nwv + 255) / 256;
+  const int w0 = t * chunk;
+  const int w1 = (w0 + chunk) < nwv ? (w0 + chunk) : nwv;
+  int local = 0;
+  for (int w = w0; w < w1; ++w) local += wcnt[(size_t)w * nr + r];
+  sm[t] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {      // Hillis-Steele inclusive scan
+    const int v = t >= off ? sm[t - off] : 0;
+    __syncthreads();
+    sm[t] += v;
+    __syncthreads();
+  }
+  int run = sm[t] - local;
+  for (int w = w0; w < w1; ++w) {
+    const int c = wcnt[(size_t)w * nr + r];
+    offs[(size_t)w * nr + r] = run;
+    run += c;
+  }
+  if (t == 255) tot[r] = sm[255];
+}
+
+struct SpVjpArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ g;
+  const float* __restrict__ rec;       // [N][S] dense records {c[DC], folded scale, W[OP]}
+  const float* __restrict__ sig2;      // [N]
+  const int2* __restrict__ pairs;
+  const int* __restrict__ tot;         // [nr]
+  float* __restrict__ part;            // [SL][V][Npad]
+  int Dreal, O, K, nr, S, Npad, SL;
+  float gscale;
+};
+
+constexpr int kSpVP = 8;               // pairs per lane held in registers
+
+// rows of x / the cotangent are 4-byte aligned only (28- and 40-byte rows): multi-dword loads with that alignment
+struct __attribute__((packed, aligned(4))) SpF4 { float v[4]; };
+struct __attribute__((packed, aligned(4))) SpF2 { float v[2]; };
+template <int N>
+__device__ __forceinline__ void sp_load_row(const float* __restrict__ p, int nreal, bool valid, float (&dst)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) dst[j] = 0.0f;
+  if (!valid) return;
+  if (nreal == N) {                              // the compiled width is the real width: whole row in 16- / 8- / 4-byte pieces
+    int j = 0;
+#pragma unroll
+    for (; j + 4 <= N; j += 4) {
+      const SpF4 t = *reinterpret_cast<const SpF4*>(p + j);
+      dst[j] = t.v[0]; dst[j + 1] = t.v[1]; dst[j + 2] = t.v[2]; dst[j + 3] = t.v[3];
+    }
+    if constexpr ((N & 3) >= 2) {
+      const SpF2 t = *reinterpret_cast<const SpF2*>(p + (N & ~3));
+      dst[N & ~3] = t.v[0]; dst[(N & ~3) + 1] = t.v[1];
+    }
+    if constexpr (N & 1) dst[N - 1] = p[N - 1];
+  } else {
+#pragma unroll
+    for (int j2 = 0; j2 < N; ++j2)
+      if (j2 < nreal) dst[j2] = p[j2];
+  }
+}
+
+// Sums of NV values over the 64 lanes by a TRANSPOSING butterfly: at every step a lane keeps one half of its values and hands
+// the other half to its partner (lane ^ 32, 16, 8, 4, 2), so NV/2 + NV/4 + ... (+ 1 for the last pair) values cross lanes
+// instead of 6 NV.  Returns the lane's value index (or -1): lanes with an even number and index < NV hold that value's total.
+// Fixed order -> deterministic.
+template <int NV>
+__device__ __forceinline__ int sp_reduce_transpose(float (&vals)[NV], int lane) {
+  static_assert(NV >= 1 && NV <= 64, "one value per lane at the end");
+  int n = NV, idx = 0, m = 32;
+#pragma unroll
+  for (int step = 0; step < 6; ++step) {         // halvings: lane ^ 32, 16, ... while more than one value is left
+    if (n > 1) {
+      const int half = (n + 1) / 2;
+      const bool up = (lane & m) != 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (i < half) {
+          const float lo_v = vals[i];
+          const float hi_v = (i + half < n) ? vals[i + half < NV ? i + half : 0] : 0.0f;
+          const float send = up ? lo_v : hi_v;
+          const float keep = up ? hi_v : lo_v;
+          vals[i] = keep + __shfl_xor(send, m);
+        }
+      }
+      idx += up ? half : 0;
+      n = half;
+      m >>= 1;
+    }
+  }
+  const int rest = 2 * m - 1;                    // lane bits not used by a halving: plain butterfly over them
+#pragma unroll
+  for (int step = 0; step < 6; ++step) {
+    if (m >= 1) {
+      vals[0] += __shfl_xor(vals[0], m);
+      m >>= 1;
+    }
+  }
+  return ((lane & rest) == 0 && idx < NV) ? idx : -1;
+}
+
+template <int D, int OP, int BC>
+__global__ __launch_bounds__(kWave) void rbf_vjp_sparse(const SpVjpArgs a) {
+  extern __shared__ float accs[];                // [K][V]
+  constexpr int V = D + 1 + OP;
+  constexpr int P = kSpVP;
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x, sl = blockIdx.y;
+  for (int i = lane; i < a.K * V; i += kWave) accs[i] = 0.0f;
+  // first pair of region r, length of its list
+  int base = 0;
+  const int rlim = r < a.nr ? r : a.nr;          // regions beyond the card's ranges have gamma == 0 (model.py:70): empty lists
+  for (int r0 = 0; r0 < rlim; r0 += kWave) {
+    int v = (r0 + lane < rlim) ? a.tot[r0 + lane] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    base += v;
+  }
+  const int Lr = r < a.nr ? a.tot[r] : 0;
+  const int i_beg = (int)((long)Lr * sl / a.SL), i_end = (int)((long)Lr * (sl + 1) / a.SL);
+  typedef const float __attribute__((address_space(4)))* crec_t;
+  for (int c0 = i_beg; c0 < i_end; c0 += kWave * P) {
+    float xq[P][D], gq[P][OP], gam[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = c0 + p * kWave + lane;
+      const bool valid = i < i_end;
+      int2 pr = make_int2(0, 0);
+      if (valid) pr = a.pairs[base + i];
+      gam[p] = __int_as_float(pr.y);             // 0 for the padding lanes: x = 0 keeps phi finite, gamma = 0 removes it
+      sp_load_row<D>(a.x + (long)pr.x * a.Dreal, a.Dreal, valid, xq[p]);
+      sp_load_row<OP>(a.g + (long)pr.x * a.O, a.O, valid, gq[p]);
+    }
+    for (int k = 0; k < a.K; ++k) {
+      const int n = r * a.K + k;
+      const crec_t rp = (crec_t)(uintptr_t)(a.rec + (size_t)n * a.S);
+      float vals[V];                             // [0, D): d centre, D: d log_sig, D + 1 + o: per-centre Dense gradient
+#pragma unroll
+      for (int v = 0; v < V; ++v) vals[v] = 0.0f;
+      const float sc = rp[D];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float diff[D], r2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          diff[j] = xq[p][j] - rp[j];
+          r2 = __builtin_fmaf(diff[j], diff[j], r2);
+        }
+        const float phi = basis_from_r2<BC>(r2, sc, 0);
+        float hb = 0.0f;
+        const float gphi = gam[p] * phi;
+#pragma unroll
+        for (int o = 0; o < OP; ++o) {
+          hb = __builtin_fmaf(gq[p][o], rp[D + 1 + o], hb);
+          vals[D + 1 + o] = __builtin_fmaf(gphi, gq[p][o], vals[D + 1 + o]);
+        }
+        const float t = hb * gam[p] * dphi_dd2_h<BC>(phi, a.gscale);
+        vals[D] = __builtin_fmaf(t, r2, vals[D]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) vals[j] = __builtin_fmaf(t, diff[j], vals[j]);
+      }
+      // the wave's sums (fixed butterfly), added to the slice's accumulators: chunks in list order
+      const int vi = sp_reduce_transpose<V>(vals, lane);
+      if (vi >= 0) accs[k * V + vi] += vals[0];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  // slab row of this slice: the centre's -2 / sigma^2 multiplies the finished sums (as in K2)
+  for (int i = lane; i < a.K * V; i += kWave) {
+    const int k = i / V, v = i - k * V;
+    const int n = r * a.K + k;
+    float val = accs[i];
+    if (v <= D) val *= -2.0f * a.sig2[n];
+    a.part[((size_t)sl * V + v) * a.Npad + n] = val;
+  }
+}
+
+template <int D, int OP>
+static int spv_launch_bc(const SpVjpArgs& a, int bc, dim3 grid, size_t lds, hipStream_t s) {
+  switch (bc) {
+    case BC_GAUSS: hipLaunchKernelGGL((rbf_vjp_sparse<D, OP, BC_GAUSS>), grid, dim3(kWave), lds, s, a); break;
+    case BC_IQ: hipLaunchKernelGGL((rbf_vjp_sparse<D, OP, BC_IQ>), grid, dim3(kWave), lds, s, a); break;
+    case BC_IMQ: hipLaunchKernelGGL((rbf_vjp_sparse<D, OP, BC_IMQ>), grid, dim3(kWave), lds, s, a); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+template <int D>
+static int spv_launch_d(const SpVjpArgs& a, int OP, int bc, dim3 grid, size_t lds, hipStream_t s) {
+  switch (OP) {
+    case 2: return spv_launch_bc<D, 2>(a, bc, grid, lds, s);
+    case 4: return spv_launch_bc<D, 4>(a, bc, grid, lds, s);
+    case 5: return spv_launch_bc<D, 5>(a, bc, grid, lds, s);
+    case 8: return spv_launch_bc<D, 8>(a, bc, grid, lds, s);
+    case 10: return spv_launch_bc<D, 10>(a, bc, grid, lds, s);
+    case 16: return spv_launch_bc<D, 16>(a, bc, grid, lds, s);
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+}
+
+bool sparse_vjp_eligible(const irbfn_net* net) {
+  return net->sp_ok && net->bclass != BC_GENERIC && net->OP <= 16 && (size_t)net->K * (net->DC + 1 + net->OP) * 4 <= 60 * 1024;
+}
+
+int sparse_vjp_slices(const irbfn_net* net, int64_t B) {
+  // slices of a region's list: about one register chunk (64 * P pairs) per wave at the expected list length, and enough
+  // waves for the chip
+  const double per_region = (double)B * net->sp_mean_active / net->n_ranges;
+  int sl = (int)(per_region / (kWave * kSpVP) + 0.999);
+  while ((long)sl * net->n_ranges < 1024 && sl < 64) ++sl;
+  return sl < 1 ? 1 : (sl > 64 ? 64 : sl);
+}
+
+// workspace of the pair lists, in bytes (after the dense plan's buffers): wcnt, offs [nwv][nr]; tot [nr]; pairs [B * cap]
+size_t sparse_vjp_workspace_bytes(const irbfn_net* net, int64_t B) {
+  const size_t nwv = (size_t)((B + kWave - 1) / kWave);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  return 2 * al(nwv * net->n_ranges * 4) + al((size_t)net->n_ranges * 4) + al((size_t)B * net->sp_cap * 8);
+}
+
+// pair lists + K2r -> slab part[SL][V][Npad]; the caller runs the slab reduce and the bias sums
+int launch_vjp_sparse(irbfn_net* net, const float* x, const float* gout, int64_t B, void* spws, float* part, int SL, int Npad,
+                      hipStream_t s) {
+  if (!sparse_vjp_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  const int nr = net->n_ranges;
+  const size_t nwv = (size_t)((B + kWave - 1) / kWave);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  char* base = static_cast<char*>(spws);
+  int* wcnt = reinterpret_cast<int*>(base);
+  int* offs = reinterpret_cast<int*>(base + al(nwv * nr * 4));
+  int* tot = reinterpret_cast<int*>(base + 2 * al(nwv * nr * 4));
+  int2* pairs = reinterpret_cast<int2*>(base + 2 * al(nwv * nr * 4) + al((size_t)nr * 4));
+  SpPairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.x = x; pa.img = net->sp_img; pa.B = (long)B; pa.Dreal = net->D; pa.nr = nr; pa.E = net->sp_E; pa.ns = net->nsplit;
+  pa.RS = net->sp_RS; pa.K = net->K; pa.cap = net->sp_cap; pa.nwv = (int)nwv; pa.wcnt = wcnt; pa.offs = offs; pa.tot = tot;
+  pa.pairs = pairs;
+  const SpImg im = sp_img_layout(nr, net->sp_RS, net->sp_E, net->K);
+  const size_t nr64 = ((size_t)nr + 63) & ~(size_t)63;
+  const size_t lds = ((size_t)im.small + (size_t)net->sp_E * kSpNT + 9 * kSpNT + (size_t)((nr + 31) / 32) * kSpNT +
+                      2 * (kSpNT / kWave) * nr64 + nr + (size_t)(kSpNT / kWave) * nr + 8) * 4;
+  if (lds > kSpMaxLds) return IRBFN_ERR_UNSUPPORTED;
+  const dim3 gridp((unsigned)((B + kSpNT - 1) / kSpNT));
+#define IRBFN_SPP(DV, FILLV)                                                                                         \
+  do {                                                                                                               \
+    auto k = sparse_pairs_kernel<DV, FILLV>;                                                                         \
+    static thread_local int attr_dev = -1;                                                                           \
+    int dev = 0;                                                                                                     \
+    IRBFN_HIP_CHECK(hipGetDevice(&dev));                                                                             \
+    if (attr_dev != dev) {                                                                                           \
+      IRBFN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)kSpMaxLds));                                                          \
+      attr_dev = dev;                                                                                                \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k, gridp, dim3(kSpNT), lds, s, pa);                                                           \
+    IRBFN_HIP_CHECK(hipGetLastError());                                                                              \
+  } while (0)
+#define IRBFN_SPP_D(FILLV)                                                                                           \
+  switch (net->DC) {                                                                                                 \
+    case 3: IRBFN_SPP(3, FILLV); break;                                                                              \
+    case 4: IRBFN_SPP(4, FILLV); break;                                                                              \
+    case 7: IRBFN_SPP(7, FILLV); break;                                                                              \
+    case 8: IRBFN_SPP(8, FILLV); break;                                                                              \
+    default: return IRBFN_ERR_UNSUPPORTED;                                                                           \
+  }
+  IRBFN_SPP_D(false)
+  hipLaunchKernelGGL(sparse_scan_kernel, dim3(nr), dim3(256), 0, s, wcnt, offs, tot, (int)nwv, nr);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  IRBFN_SPP_D(true)
+#undef IRBFN_SPP_D
+#undef IRBFN_SPP
+  SpVjpArgs va;
+  memset(&va, 0, sizeof(va));
+  va.x = x; va.g = gout; va.rec = net->rec; va.sig2 = net->sig2; va.pairs = pairs; va.tot = tot; va.part = part;
+  va.Dreal = net->D; va.O = net->O; va.K = net->K; va.nr = nr; va.S = net->S; va.Npad = Npad; va.SL = SL;
+  va.gscale = gauss_scale(net->basis);
+  const dim3 gridv(net->R, SL);               // every region gets its slab rows (zeros where no query is live)
+  const size_t ldsv = (size_t)net->K * (net->DC + 1 + net->OP) * 4;
+  int rc;
+  switch (net->DC) {
+    case 3: rc = spv_launch_d<3>(va, net->OP, net->bclass, gridv, ldsv, s); break;
+    case 4: rc = spv_launch_d<4>(va, net->OP, net->bclass, gridv, ldsv, s); break;
+    case 7: rc = spv_launch_d<7>(va, net->OP, net->bclass, gridv, ldsv, s); break;
+    case 8: rc = spv_launch_d<8>(va, net->OP, net->bclass, gridv, ldsv, s); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
   }
   return rc;
 }

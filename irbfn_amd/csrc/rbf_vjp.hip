@@ -360,6 +360,9 @@ struct VjpPlan {
   int QS;
   bool use_h;      // K2h (matrix-core VJP) instead of K2
   int CT;
+  bool use_sp;     // K2r (region-sparse VJP, rbf_sparse.hip) instead of K2
+  int SL;          // K2r: slices per region (<= QSB slabs are allocated)
+  size_t off_sp, off_sp_part;   // K2r: pair lists, slabs
 };
 
 static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
@@ -393,6 +396,17 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   p.CT = net->opt[IRBFN_OPT_VJP_F16_CT] == 4 ? 4 : 2;
   p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * vjph_block_bytes(net) : 0);
   p.off_misc = off;  off += al((size_t)(p.bias_blocks + 8) * sizeof(float));
+  // K2r: several regions with a sparse gate (automatic where the forward takes K1r; IRBFN_VJP_K2R forces it where eligible)
+  p.use_sp = sparse_vjp_eligible(net) && (vk == IRBFN_VJP_K2R || (vk == IRBFN_VJP_AUTO && sparse_preferred(net, B)));
+  p.SL = 0;
+  p.off_sp = off;
+  p.off_sp_part = off;
+  if (sparse_vjp_eligible(net)) {
+    off += al(sparse_vjp_workspace_bytes(net, B));
+    p.SL = sparse_vjp_slices(net, B);
+    p.off_sp_part = off;                          // K2r's own slabs [SL][V][Npad]
+    off += al((size_t)p.SL * p.V * p.Npad * sizeof(float));
+  }
   if (p.use_h) {
     // fewer, longer query slices than K2 (3 waves per SIMD resident): halves the slab traffic of the reduce kernel
     const long gh = (net->N + 16 * p.CT - 1) / (16 * p.CT);
@@ -720,6 +734,25 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     return IRBFN_OK;
   }
 
+  if (p.use_sp && !gamma_ext) {
+    // K2r: pair lists per region -> one wave per (region, slice) -> the same fixed-order slab reduce; no query packing
+    float* sp_part = reinterpret_cast<float*>(base + p.off_sp_part);
+    int rcs = launch_vjp_sparse(net, x, gout, B, base + p.off_sp, sp_part, p.SL, p.Npad, s);
+    if (rcs != IRBFN_ERR_UNSUPPORTED) {
+      if (rcs != IRBFN_OK) return rcs;
+      rcs = launch_vjp_reduce(net, sp_part, g_centers, g_log_sigs, g_kernel, p.SL, p.V, p.Npad, s);
+      if (rcs != IRBFN_OK) return rcs;
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
+                         (long)B, net->O, p.rows_per_block, (float*)nullptr);
+      IRBFN_HIP_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
+      IRBFN_HIP_CHECK(hipGetLastError());
+      return IRBFN_OK;
+    }
+    if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2R) return IRBFN_ERR_UNSUPPORTED;
+  } else if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2R && !gamma_ext) {
+    return IRBFN_ERR_UNSUPPORTED;                  // a forced kernel that cannot take the net
+  }
   float* qrec = reinterpret_cast<float*>(base + p.off_qrec);
   {
     const size_t glds = ((size_t)net->nsplit * net->max_ranges * kWave + (size_t)net->gate().n_ranges * net->nsplit) * sizeof(float);

@@ -136,3 +136,90 @@ def test_sparse_tick_equals_forward_then_rollout(gpu, run, mode):
         else:
             ref_states = dynamics.integrate_st_mult(torch.cat([s0, u], dim=1), configs.DYN_PARAMS)
         assert torch.equal(states, ref_states.reshape(states.shape))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K2r: region-sparse parameter VJP
+# ---------------------------------------------------------------------------------------------------------------
+LEAVES = (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias"))
+
+
+@pytest.mark.parametrize("run", RUNS)
+@pytest.mark.parametrize("B", [1, 63, 257, 5000])
+def test_sparse_vjp_matches_dense_and_oracle(gpu, run, B):
+    """Four gradient leaves of the pair-list VJP against the dense gated K2 (same terms, other order) and the float64 C
+    restatement of the reference's backward (oracle_wcrbf_vjp); ragged batches; border queries (gamma strictly inside
+    (0, 1) in several regions); bitwise reproducible (no position comes from an atomic)."""
+    import torch
+    from oracle import c_oracle as co
+    cfg, P, *_ = load_ckpt_fixture(run)
+    P32 = {"params": {g: {n: np.asarray(v, np.float32) for n, v in d.items()} for g, d in P["params"].items()}}
+    rng = np.random.default_rng(B)
+    for border in (False, True):
+        x = _queries(cfg, B, seed=B + 1, border=border)
+        g = rng.normal(size=(B, cfg["out_features"])).astype(np.float32)
+        xt, gt = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+        ref = co.wcrbf_vjp(cfg, P32, x, g, np.float64)["params"]
+        net = WCRBFNet.from_config(cfg)
+        net.set_options(vjp_kernel=_lib.VJP_K2R)
+        sp = net.vjp(P32, xt, gt)["params"]
+        sp2 = net.vjp(P32, xt, gt)["params"]
+        net.set_options(vjp_kernel=_lib.VJP_K2)
+        dn = net.vjp(P32, xt, gt)["params"]
+        for grp, name in LEAVES:
+            a, b, d = sp[grp][name], sp2[grp][name], dn[grp][name]
+            assert torch.equal(a, b), (run, B, name)                          # deterministic
+            r = ref[grp][name]
+            scale = np.abs(r).max() + 1e-30
+            ea = np.abs(a.cpu().numpy() - r).max() / scale
+            ed = np.abs(d.cpu().numpy() - r).max() / scale
+            assert ea <= 5e-5, (run, B, border, name, ea, ed)                 # the bound the dense kernels are held to
+            assert np.abs(a.cpu().numpy() - d.cpu().numpy()).max() <= 2e-5 * scale, (run, B, border, name)
+
+
+def test_sparse_vjp_nan_query_and_forced_kernel_errors(gpu):
+    import torch
+    cfg, P, *_ = load_ckpt_fixture("dnmpc_128regions")
+    P32 = {"params": {g: {n: np.asarray(v, np.float32) for n, v in d.items()} for g, d in P["params"].items()}}
+    x = _queries(cfg, 700, seed=2)
+    x[11, :] = np.nan                                   # more live factors than any finite query: the list is capped
+    g = np.random.default_rng(0).normal(size=(700, 10)).astype(np.float32)
+    net = WCRBFNet.from_config(cfg)
+    net.set_options(vjp_kernel=_lib.VJP_K2R)
+    out = net.vjp(P32, x, g)["params"]
+    assert np.isnan(out["linear"]["kernel"]).any()      # NaN reaches the gradients, as in the dense kernel / jax
+    # a one-region net cannot take the sparse kernels: the forced option fails loudly instead of falling back
+    net1 = WCRBFNet.from_config(configs.model_card(1))
+    net1.set_options(vjp_kernel=_lib.VJP_K2R)
+    with pytest.raises(Exception):
+        net1.vjp(configs.synth_params(1), configs.synth_queries(1, B=100), configs.synth_cotangent(1, B=100))
+    net1.set_options(fwd_kernel=_lib.FWD_K1R)
+    with pytest.raises(Exception):
+        net1.apply(configs.synth_params(1), configs.synth_queries(1, B=100))
+
+
+def test_train_step_on_the_128_region_net_uses_the_sparse_kernels(gpu):
+    """train_step_fullint (scripts/train_nmpc.py:303-421) at the reference's batch size on its 128-region planner:
+    automatic dispatch = K1r forward + K2r VJP; two steps equal the dense kernels' two steps to float32 reordering."""
+    import torch
+    from irbfn_amd import train
+    cfg, P, *_ = load_ckpt_fixture("dnmpc_128regions")
+    P32 = {"params": {g: {n: np.asarray(v, np.float32) for n, v in d.items()} for g, d in P["params"].items()}}
+    B = 20000
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(_queries(cfg, B, seed=8)).cuda()
+    y = torch.from_numpy(np.hstack([rng.normal(size=(B, 5)) * 2, rng.normal(size=(B, 5)) * 0.5]).astype(np.float32)).cuda()
+    res = {}
+    for name, kf, kv in (("sparse", _lib.FWD_AUTO, _lib.VJP_AUTO), ("dense", _lib.FWD_K1, _lib.VJP_K2)):
+        net = WCRBFNet.from_config(cfg)
+        net.set_options(fwd_kernel=kf, vjp_kernel=kv)
+        st = train.TrainState.create(net, P32, lr=1e-3, max_grad_norm=1.0)
+        losses = []
+        for _ in range(2):
+            st, loss = train.train_step_fullint(st, x, y)
+            losses.append(float(loss))
+        if name == "sparse":
+            assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<")
+        res[name] = (losses, st.flat.clone())
+    assert np.allclose(res["sparse"][0], res["dense"][0], rtol=2e-5)
+    assert (res["sparse"][1] - res["dense"][1]).abs().max() <= 1e-4 * res["dense"][1].abs().max()
