@@ -14,6 +14,9 @@ constexpr int kMaxD = 8;
 // blocks (= partial sums) of every two-stage loss / norm reduction: the size of the caller's `partials` buffer
 // (irbfn_train_loss_partials) -- train_step.hip and the cross-entropy of the cluster gate (rbf_vjp.hip) share it
 constexpr int kRedBlocks = 256;
+// the loss / seed kernels (one roll-out + adjoint per row) run one row per thread up to this many blocks of 256: the
+// caller's `partials` buffer holds kSeedBlocksMax floats
+constexpr int kSeedBlocksMax = 1024;
 
 // basis classes the hot loops are specialised on
 enum BasisClass : int { BC_GAUSS = 0, BC_IQ = 1, BC_IMQ = 2, BC_GENERIC = 3 };

@@ -40,7 +40,10 @@
 
 namespace irbfn {
 
-constexpr int kSpNT = 256;              // lanes (= queries) per workgroup
+#ifndef IRBFN_SP_NT
+#define IRBFN_SP_NT 256
+#endif
+constexpr int kSpNT = IRBFN_SP_NT;      // lanes (= queries) per workgroup
 constexpr int kSpMaxE = 32;             // factor entries (bits of the activity mask)
 constexpr int kSpMaxCap = 96;           // list capacity per query
 constexpr int kSpMaxRegions = 1024;     // the scan is linear in the number of regions
@@ -74,9 +77,9 @@ __host__ __device__ inline SpImg sp_img_layout(int nr, int RS, int E, int K) {
 struct SpLds {
   int ftab, xs, part, hw, flat_r, flat_q, wsum, total;
 };
-__host__ __device__ inline SpLds sp_lds_layout(int img_total, int nr, int E, int cap, int wide) {
+__host__ __device__ inline SpLds sp_lds_layout(int img_in_lds, int nr, int E, int cap, int wide) {
   SpLds l;
-  int o = img_total;
+  int o = img_in_lds;                            // whole image, or the small tables only (centre table read from global)
   l.ftab = o; o += E * kSpNT;
   l.xs = o;   o += 9 * kSpNT;                                    // x tile, pitch D|1 <= 9
   o = (o + 3) & ~3;
@@ -230,7 +233,7 @@ struct SpArgs {
   const float* __restrict__ bias;
   const float* __restrict__ img;       // sp_img_layout
   long B;
-  int Dreal, O, K, nr, E, ns, cap, RS, basis, wide_list;
+  int Dreal, O, K, nr, E, ns, cap, RS, basis, wide_list, gc;
   const int* __restrict__ mirror;
   int sv0;
   // fused roll-out (ROLL)
@@ -249,15 +252,18 @@ __device__ unsigned long long g_sp_stamps[32];
 #define IRBFN_SP_STAMP(n) do { } while (0)
 #endif
 
-template <int D, int OP, int BC, bool ROLL>
+// GC: the centre table stays in global memory (L1 / L2 resident: 43 KB on the 128-region planner) and the lanes gather their
+// centres from there -- 47 KB of LDS per workgroup instead of 93, i.e. THREE workgroups per CU instead of one.  The kernel is
+// a chain of dependent phases with one wave per SIMD; co-resident workgroups are what hides it.
+template <int D, int OP, int BC, bool ROLL, bool GC>
 __global__ __launch_bounds__(kSpNT) void rbf_fwd_sparse(const SpArgs a) {
   extern __shared__ float lds[];
   constexpr int NT = kSpNT;
   constexpr int EW = (D + 1 + 3) & ~3;
   constexpr int XP = D | 1;                      // odd pitch of the x tile
   const SpImg IM = sp_img_layout(a.nr, a.RS, a.E, a.K);
-  const SpLds L = sp_lds_layout(IM.total, a.nr, a.E, a.cap, a.wide_list);
-  const float* ctab_s = lds + IM.ctab;
+  const SpLds L = sp_lds_layout(GC ? IM.small : IM.total, a.nr, a.E, a.cap, a.wide_list);
+  const float* ctab_s = GC ? nullptr : lds + IM.ctab;
   const unsigned* idx_s = reinterpret_cast<const unsigned*>(lds + IM.idx);
   const unsigned* req_s = reinterpret_cast<const unsigned*>(lds + IM.req);
   const float* ent_s = lds + IM.ent;
@@ -310,8 +316,10 @@ __global__ __launch_bounds__(kSpNT) void rbf_fwd_sparse(const SpArgs a) {
   __syncthreads();
   // ---- the centre table (43 KB on the 128-region planner: ~2 us at the LDS-DMA rate of one CU) is requested now and lands
   // while the lanes evaluate their gates; nobody reads it before the barrier in front of the rounds
-  for (int v = IM.small / 256 + wave; v < IM.total / 256; v += NT / kWave)
-    __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
+  if constexpr (!GC) {
+    for (int v = IM.small / 256 + wave; v < IM.total / 256; v += NT / kWave)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
+  }
 
   // ---- this lane's query: factors of every (dimension, range) entry, activity mask.  Groups of four: the four entry
   // reads are in flight together (a store to the factor column may alias them for the compiler: one at a time, every
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(kSpNT) void rbf_fwd_sparse(const SpArgs a) {
     float pacc[OP];
 #pragma unroll
     for (int o = 0; o < OP; ++o) pacc[o] = 0.0f;
-    const float* cp = ctab_s + r * a.RS;
+    const float* cp = (GC ? a.img + IM.ctab : ctab_s) + r * a.RS;
     auto load2 = [&](int kk, float (&cv)[2][EW], float (&wv)[2][4 * WV]) {      // centres kk, kk + 1 and their weight rows
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -626,9 +634,9 @@ __global__ __launch_bounds__(kSpNT) void rbf_fwd_sparse(const SpArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, int OP, int BC, bool ROLL>
-static int sp_launch_one(const SpArgs& a, size_t lds, hipStream_t s, int* grid_out) {
-  auto k = rbf_fwd_sparse<D, OP, BC, ROLL>;
+template <int D, int OP, int BC, bool ROLL, bool GC>
+static int sp_launch_gc(const SpArgs& a, size_t lds, hipStream_t s, int* grid_out) {
+  auto k = rbf_fwd_sparse<D, OP, BC, ROLL, GC>;
   // the attribute call is a slow host call (it made back-to-back launches host-bound at ~30 us each): once per
   // instance and device is enough -- the largest size any card may ask for
   static thread_local int attr_dev = -1;
@@ -644,6 +652,11 @@ static int sp_launch_one(const SpArgs& a, size_t lds, hipStream_t s, int* grid_o
   IRBFN_HIP_CHECK(hipGetLastError());
   *grid_out = (int)grid;
   return IRBFN_OK;
+}
+
+template <int D, int OP, int BC, bool ROLL>
+static int sp_launch_one(const SpArgs& a, size_t lds, hipStream_t s, int* grid_out) {
+  return a.gc ? sp_launch_gc<D, OP, BC, ROLL, true>(a, lds, s, grid_out) : sp_launch_gc<D, OP, BC, ROLL, false>(a, lds, s, grid_out);
 }
 
 template <int D, int OP, bool ROLL>
@@ -692,7 +705,20 @@ int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B,
   a.cap = net->sp_cap; a.RS = net->sp_RS; a.basis = net->basis; a.wide_list = net->n_ranges > 256 ? 1 : 0;
   a.mirror = mirror; a.sv0 = sv0;
   if (roll) { a.state0 = state0; a.states = states; a.T = T; a.mode = mode; a.dp = *dp; }
-  const SpLds L = sp_lds_layout(sp_img_layout(a.nr, a.RS, a.E, a.K).total, a.nr, a.E, a.cap, a.wide_list);
+  // Where the centre table lives.  One workgroup per CU is all that fits with the table in LDS (93 KB on the 128-region
+  // planner): best while the launch has at most one workgroup per CU (B = 65536: 22.2 vs 23.4 us; the tick 27.5 vs 37.4).
+  // Beyond that the workgroups would queue up in rounds -- with the table gathered from global memory (L2-resident) three
+  // fit per CU and the whole launch is resident at once (train step at the reference's batch of 80000: 135 vs 149 us).
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    IRBFN_HIP_CHECK(hipGetDevice(&dev));
+    IRBFN_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  a.gc = ((B + kSpNT - 1) / kSpNT > n_cu) ? 1 : 0;
+  const SpImg imh = sp_img_layout(a.nr, a.RS, a.E, a.K);
+  const SpLds L = sp_lds_layout(a.gc ? imh.small : imh.total, a.nr, a.E, a.cap, a.wide_list);
   size_t lds = (size_t)L.total * 4;
   if (roll) lds = std::max(lds, (size_t)kSpNT * 65 * 4);
   if (lds > kSpMaxLds) return IRBFN_ERR_UNSUPPORTED;
@@ -707,8 +733,8 @@ int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B,
     default: rc = IRBFN_ERR_UNSUPPORTED;
   }
   if (rc == IRBFN_OK) {
-    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_sparse<D=%d,OP=%d,BC=%d,ROLL=%d>", net->DC, net->sp_OPS,
-             net->bclass, (int)roll);
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_sparse<D=%d,OP=%d,BC=%d,ROLL=%d,GC=%d>", net->DC, net->sp_OPS,
+             net->bclass, (int)roll, a.gc);
     net->last_grid = grid;
     net->last_block = kSpNT;
   }
@@ -721,24 +747,26 @@ int launch_forward_sparse(irbfn_net* net, const float* x, float* out, int64_t B,
 // ===============================================================================================================
 // The dense K2 streams EVERY query past every centre (lane = centre, 206 us for the 128-region planner at the
 // reference's batch of 80000, plus 30-60 us of query packing).  Here the (query, region) pairs with gamma != 0 -- 3.6 per
-// query -- are listed per REGION by a stable counting sort (no position comes from an atomic: the order of a region's list,
-// hence the order of every sum, is fixed by the batch order -> bitwise reproducible gradients):
-//   sparse_pairs_kernel<COUNT>  per wave of 64 queries: number of hits per region            -> wcnt[wave][region]
-//   sparse_scan_kernel          per region: exclusive prefix over the waves, region totals   -> offs[wave][region], tot[region]
-//   sparse_pairs_kernel<FILL>   same scan again: pair (query index, gamma) -> pairs[base[r] + offs[wave][r] + rank in wave]
-//   rbf_vjp_sparse              one wave per (region, slice of its list): lanes = pairs (P per lane in registers: x, cotangent
-//                               row, gamma), loop over the region's K centres (wave-uniform: scalar loads), per centre the D + 1
-//                               + O sums over the wave's pairs by a fixed butterfly, accumulated per slice in LDS -> slab
+// query -- are listed per REGION, in batch order (no position comes from an atomic: the order of a region's list, hence the
+// order of every sum, is fixed -> bitwise reproducible gradients):
+//   sparse_pairs_kernel   per block of 256 queries: the block's pairs {query index, gamma}, sorted by region (stable), into
+//                         the block's own segment of the pair buffer; per (block, region): count and offset in the segment
+//   sparse_scan_kernel    per region: exclusive prefix of the counts over the blocks, region totals
+//   rbf_vjp_sparse        one wave per (region, slice of its list): pair i of the region = pair (i - prefix) of the block
+//                         found by binary search in the region's prefix row; lanes = pairs (P per lane in registers: x,
+//                         cotangent row, gamma), loop over the region's K centres (wave-uniform: scalar loads), per centre the
+//                         D + 1 + O sums over the wave's pairs by a fixed butterfly, accumulated per slice in LDS -> slab
 //   vjp_reduce_kernel (+ regions)  the dense path's fixed-order slab reduce (rbf_vjp.hip)
+// (A first version counted, scanned and then re-ran the whole gate evaluation to scatter the pairs to their final places:
+// that second pass cost 28 us of the 94 us VJP.)
 struct SpPairArgs {
   const float* __restrict__ x;
   const float* __restrict__ img;
   long B;
-  int Dreal, nr, E, ns, RS, K, cap, nwv;
-  int* __restrict__ wcnt;              // [nwv][nr]
-  const int* __restrict__ offs;        // [nwv][nr]  (FILL)
-  const int* __restrict__ tot;         // [nr]       (FILL)
-  int2* __restrict__ pairs;            // {query index, gamma bits}
+  int Dreal, nr, E, ns, RS, K, cap, nblk;
+  int* __restrict__ cnt;               // [nblk][nr] pairs of (block, region)
+  int* __restrict__ loff;              // [nblk][nr] their offset inside the block's segment
+  int2* __restrict__ pairs;            // [nblk][NT * cap] {query index, gamma bits}
 };
 
 // bit u of every lane's word -> ballot -> lane LB + u of (mlo, mhi).  v_writelane_b32 takes ONE scalar register (constant-bus
@@ -749,7 +777,7 @@ struct SpTranspose {
     const unsigned long long bal = __ballot((h >> U) & 1u);
     // gfx940+: a VALU that reads an SGPR a VALU has just written (the ballot's v_cmp) needs 2 wait states.  hipcc inserts them
     // for its own instructions, never inside inline asm: without the s_nop the lane received a STALE mask now and then
-    // (count and fill passes disagreed -> pairs read from unwritten slots -> memory fault on the second call).
+    // (two passes disagreed -> pairs read from unwritten slots -> memory fault on the second call).
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
                  : "+v"(mlo), "+v"(mhi)
                  : "s"((unsigned)bal), "s"((unsigned)(bal >> 32)), "n"(LB + U));
@@ -761,10 +789,11 @@ struct SpTranspose<LB, 32> {
   static __device__ __forceinline__ void run(unsigned, unsigned&, unsigned&) {}
 };
 
-template <int D, bool FILL>
+template <int D>
 __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a) {
   extern __shared__ float lds[];
   constexpr int NT = kSpNT;
+  constexpr int NW = NT / kWave;
   constexpr int XP = D | 1;
   const SpImg IM = sp_img_layout(a.nr, a.RS, a.E, a.K);
   const unsigned* idx_s = reinterpret_cast<const unsigned*>(lds + IM.idx);
@@ -775,9 +804,10 @@ __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a)
   float* ftab = lds + IM.small;                  // [E][NT]
   float* xs = ftab + a.E * NT;                   // [NT][XP]
   unsigned* hw_s = reinterpret_cast<unsigned*>(xs + 9 * NT);          // [nwords][NT] hit words of the lanes
-  uint2* masks_s = reinterpret_cast<uint2*>(hw_s + nwords * NT);      // FILL: [NT / 64][nr64] lanes of the wave that hit region r
-  int* base_s = reinterpret_cast<int*>(masks_s + (NT / kWave) * nr64);   // FILL: [nr] first pair of each region
-  int* woffs_s = base_s + a.nr;                  // FILL: [NT / 64][nr] this wave's offset inside each region's list
+  uint2* masks_s = reinterpret_cast<uint2*>(hw_s + nwords * NT);      // [NW][nr64] lanes of the wave that hit region r
+  int* woff_s = reinterpret_cast<int*>(masks_s + NW * nr64);          // [NW][nr64] pairs of (block, r) in earlier waves
+  int* loff_s = woff_s + NW * nr64;              // [nr64] offset of (block, r) in the block's segment
+  int* scan_s = loff_s + nr64;                   // [NW + 1]
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
@@ -785,7 +815,6 @@ __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a)
   const long left = a.B - row0;
   const int nvalid = left < NT ? (int)left : NT;
   const int Dr = a.Dreal;
-  const long wv = (long)blockIdx.x * (NT / kWave) + wave;     // this wave's unit (64 consecutive queries)
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   {
@@ -798,27 +827,8 @@ __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a)
     }
     const unsigned char* gimg = reinterpret_cast<const unsigned char*>(a.img) + lane * 16;
     unsigned char* limg = reinterpret_cast<unsigned char*>(lds);
-    for (int v = wave; v < IM.small / 256; v += NT / kWave)
+    for (int v = wave; v < IM.small / 256; v += NW)
       __builtin_amdgcn_global_load_lds((gptr_t)(gimg + v * 1024), (lptr_t)(limg + v * 1024), 16, 0, 0);
-    if constexpr (FILL) {
-      if (wv < a.nwv)
-        for (int r = lane; r < a.nr; r += kWave) woffs_s[wave * a.nr + r] = a.offs[wv * a.nr + r];
-      if (wave == 0) {                           // region bases: exclusive prefix of the totals, 64 regions per step
-        int run = 0;
-        for (int r0 = 0; r0 < a.nr; r0 += kWave) {
-          const int r = r0 + lane;
-          const int v = r < a.nr ? a.tot[r] : 0;
-          int incl = v;
-#pragma unroll
-          for (int off = 1; off < kWave; off <<= 1) {
-            const int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-          }
-          if (r < a.nr) base_s[r] = run + incl - v;
-          run += __shfl(incl, kWave - 1);
-        }
-      }
-    }
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       const int i = tid + u * NT;
@@ -848,13 +858,13 @@ __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (e0 + u < a.E) {
-        if constexpr (FILL) ftab[(e0 + u) * NT + tid] = f[u];
+        ftab[(e0 + u) * NT + tid] = f[u];
         M |= (f[u] != 0.0f ? 1u : 0u) << (e0 + u);
       }
     }
   }
   // hit words (as the forward), and their TRANSPOSE: for every region the 64-bit mask of the wave's lanes that hit it.
-  // Bit u of a word -> one ballot -> lane (r mod 64) of a register pair: 5 instructions per region, no branch.  The mask
+  // Bit u of a word -> one ballot -> lane (r mod 64) of a register pair: 4 instructions per region, no branch.  The mask
   // gives the wave's count of a region (popcount) and a lane's rank in it (popcount below the lane): a stable order.
   int cnt = 0;
   unsigned mlo = 0, mhi = 0;
@@ -873,54 +883,86 @@ __global__ __launch_bounds__(kSpNT) void sparse_pairs_kernel(const SpPairArgs a)
     if (tid >= nvalid) h = 0;
     while (cnt + __builtin_popcount(h) > a.cap) h &= ~(0x80000000u >> __builtin_clz(h));     // as the forward (NaN queries)
     cnt += __builtin_popcount(h);
-    if constexpr (FILL) hw_s[w * NT + tid] = h;
+    hw_s[w * NT + tid] = h;
     if (w & 1) SpTranspose<32, 0>::run(h, mlo, mhi);
     else SpTranspose<0, 0>::run(h, mlo, mhi);
     if ((w & 1) == 1 || w == nwords - 1) {       // 64 regions done: lane l holds the mask of region (w / 2) * 64 + l
-      const int r = (w >> 1) * 64 + lane;
-      if constexpr (!FILL) {
-        if (wv < a.nwv && r < a.nr) a.wcnt[wv * a.nr + r] = __builtin_popcount(mlo) + __builtin_popcount(mhi);
-      } else {
-        masks_s[wave * nr64 + r] = make_uint2(mlo, mhi);
-      }
+      masks_s[wave * nr64 + (w >> 1) * 64 + lane] = make_uint2(mlo, mhi);
       mlo = 0; mhi = 0;
     }
   }
-  if constexpr (FILL) {
-    // each lane walks its own hits: rank from the region's mask, gamma from the region's factors, position, store
-    for (int w = 0; w < nwords; ++w) {
-      unsigned h = hw_s[w * NT + tid];
-      while (h != 0) {
-        const int r = w * 32 + __builtin_ctz(h);
-        h &= h - 1;
-        const uint2 mk = masks_s[wave * nr64 + r];
-        const uint2 iw = *reinterpret_cast<const uint2*>(idx_s + r * 2);
-        const int pos0 = base_s[r] + woffs_s[wave * a.nr + r];
-        const int rank = __builtin_amdgcn_mbcnt_hi(mk.y, __builtin_amdgcn_mbcnt_lo(mk.x, 0u));
-        float g = 1.0f;                          // model.py:88-93, dimension order: the gamma of every other kernel, bit for bit
+  __syncthreads();
+  // (block, region): pairs in the earlier waves of the block, block count, offset in the segment (exclusive scan over r)
+  int run_base = 0;
+  for (int r0 = 0; r0 < nr64; r0 += NT) {
+    const int r = r0 + tid;
+    int tot = 0;
+    if (r < nr64) {
 #pragma unroll
-        for (int d = 0; d < kMaxSplit; ++d) {
-          if (d < a.ns) {
-            const unsigned e = ((d < 4 ? iw.x : iw.y) >> (8 * (d & 3))) & 0xFFu;
-            g *= ftab[e * NT + tid];
-          }
-        }
-        a.pairs[pos0 + rank] = make_int2((int)(row0 + tid), __float_as_int(g));
+      for (int w = 0; w < NW; ++w) {
+        const uint2 mk = masks_s[w * nr64 + r];
+        woff_s[w * nr64 + r] = tot;
+        tot += __builtin_popcount(mk.x) + __builtin_popcount(mk.y);
       }
+    }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (lane == kWave - 1) scan_s[wave] = incl;
+    __syncthreads();
+    int wb = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int v = scan_s[w];
+      wb += w < wave ? v : 0;
+      all += v;
+    }
+    if (r < nr64) loff_s[r] = run_base + wb + incl - tot;
+    if (r < a.nr) {
+      a.cnt[(size_t)blockIdx.x * a.nr + r] = tot;
+      a.loff[(size_t)blockIdx.x * a.nr + r] = run_base + wb + incl - tot;
+    }
+    run_base += all;
+    __syncthreads();
+  }
+  // each lane walks its own hits: rank from the region's mask, gamma from the region's factors, position, store
+  int2* seg = a.pairs + (size_t)blockIdx.x * NT * a.cap;
+  for (int w = 0; w < nwords; ++w) {
+    unsigned h = hw_s[w * NT + tid];
+    while (h != 0) {
+      const int r = w * 32 + __builtin_ctz(h);
+      h &= h - 1;
+      const uint2 mk = masks_s[wave * nr64 + r];
+      const uint2 iw = *reinterpret_cast<const uint2*>(idx_s + r * 2);
+      const int pos0 = loff_s[r] + woff_s[wave * nr64 + r];
+      const int rank = __builtin_amdgcn_mbcnt_hi(mk.y, __builtin_amdgcn_mbcnt_lo(mk.x, 0u));
+      float g = 1.0f;                            // model.py:88-93, dimension order: the gamma of every other kernel, bit for bit
+#pragma unroll
+      for (int d = 0; d < kMaxSplit; ++d) {
+        if (d < a.ns) {
+          const unsigned e = ((d < 4 ? iw.x : iw.y) >> (8 * (d & 3))) & 0xFFu;
+          g *= ftab[e * NT + tid];
+        }
+      }
+      seg[pos0 + rank] = make_int2((int)(row0 + tid), __float_as_int(g));
     }
   }
 }
 
-// per region: exclusive prefix of the per-wave counts (the order of a region's list = batch order), and the total
-__global__ __launch_bounds__(256) void sparse_scan_kernel(const int* __restrict__ wcnt, int* __restrict__ offs,
-                                                          int* __restrict__ tot, int nwv, int nr) {
+// per region: exclusive prefix of the per-block counts (the order of a region's list = batch order) as a contiguous row
+// pre[r][0..nblk) for the binary search of K2r, and the region's total
+__global__ __launch_bounds__(256) void sparse_scan_kernel(const int* __restrict__ cnt, int* __restrict__ pre,
+                                                          int* __restrict__ tot, int nblk, int nr) {
   __shared__ int sm[256];
   const int r = blockIdx.x, t = threadIdx.x;
-  const int chunk = (nwv + 255) / 256;
+  const int chunk = (nblk + 255) / 256;
   const int w0 = t * chunk;
-  const int w1 = (w0 + chunk) < nwv ? (w0 + chunk) : nwv;
+  const int w1 = (w0 + chunk) < nblk ? (w0 + chunk) : nblk;
   int local = 0;
-  for (int w = w0; w < w1; ++w) local += wcnt[(size_t)w * nr + r];
+  for (int w = w0; w < w1; ++w) local += cnt[(size_t)w * nr + r];
   sm[t] = local;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {      // Hillis-Steele inclusive scan
@@ -931,8 +973,8 @@ __global__ __launch_bounds__(256) void sparse_scan_kernel(const int* __restrict_
   }
   int run = sm[t] - local;
   for (int w = w0; w < w1; ++w) {
-    const int c = wcnt[(size_t)w * nr + r];
-    offs[(size_t)w * nr + r] = run;
+    const int c = cnt[(size_t)w * nr + r];
+    pre[(size_t)r * nblk + w] = run;
     run += c;
   }
   if (t == 255) tot[r] = sm[255];
@@ -943,14 +985,19 @@ struct SpVjpArgs {
   const float* __restrict__ g;
   const float* __restrict__ rec;       // [N][S] dense records {c[DC], folded scale, W[OP]}
   const float* __restrict__ sig2;      // [N]
-  const int2* __restrict__ pairs;
-  const int* __restrict__ tot;         // [nr]
+  const int2* __restrict__ pairs;      // [nblk][NT * cap] region-sorted pairs of every query block
+  const int* __restrict__ tot;         // [nr] pairs of the region
+  const int* __restrict__ pre;         // [nr][nblk] exclusive prefix of the block counts
+  const int* __restrict__ loff;        // [nblk][nr] offset of (block, region) in the block's segment
   float* __restrict__ part;            // [SL][V][Npad]
-  int Dreal, O, K, nr, S, Npad, SL;
+  int Dreal, O, K, nr, S, Npad, SL, nblk, nsteps, segsize;
   float gscale;
 };
 
-constexpr int kSpVP = 8;               // pairs per lane held in registers
+#ifndef IRBFN_SP_VP
+#define IRBFN_SP_VP 8
+#endif
+constexpr int kSpVP = IRBFN_SP_VP;     // pairs per lane held in registers
 
 // rows of x / the cotangent are 4-byte aligned only (28- and 40-byte rows): multi-dword loads with that alignment
 struct __attribute__((packed, aligned(4))) SpF4 { float v[4]; };
@@ -1026,26 +1073,37 @@ __global__ __launch_bounds__(kWave) void rbf_vjp_sparse(const SpVjpArgs a) {
   const int lane = threadIdx.x;
   const int r = blockIdx.x, sl = blockIdx.y;
   for (int i = lane; i < a.K * V; i += kWave) accs[i] = 0.0f;
-  // first pair of region r, length of its list
-  int base = 0;
-  const int rlim = r < a.nr ? r : a.nr;          // regions beyond the card's ranges have gamma == 0 (model.py:70): empty lists
-  for (int r0 = 0; r0 < rlim; r0 += kWave) {
-    int v = (r0 + lane < rlim) ? a.tot[r0 + lane] : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    base += v;
-  }
+  // length of the region's list (regions beyond the card's ranges have gamma == 0, model.py:70: empty)
   const int Lr = r < a.nr ? a.tot[r] : 0;
   const int i_beg = (int)((long)Lr * sl / a.SL), i_end = (int)((long)Lr * (sl + 1) / a.SL);
+  const int* pre_r = a.pre + (size_t)(r < a.nr ? r : 0) * a.nblk;
   typedef const float __attribute__((address_space(4)))* crec_t;
   for (int c0 = i_beg; c0 < i_end; c0 += kWave * P) {
     float xq[P][D], gq[P][OP], gam[P];
+    // pair i of the region = pair (i - pre[blk]) of the last block whose prefix is <= i: P binary searches side by side
+    int lo_b[P], hi_b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { lo_b[p] = 0; hi_b[p] = a.nblk; }
+    for (int st = 0; st < a.nsteps; ++st) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i0 = c0 + p * kWave + lane;
+        const int i = i0 < i_end ? i0 : i_beg;   // padding lanes search for a valid pair (their result is not used)
+        const int mid = (lo_b[p] + hi_b[p]) >> 1;                // invariant: pre[lo] <= i, pre[hi] > i (or hi == nblk)
+        const bool le = pre_r[mid] <= i;                         // mid == lo once hi - lo == 1: nothing changes any more
+        lo_b[p] = le ? mid : lo_b[p];
+        hi_b[p] = (!le && mid > lo_b[p]) ? mid : hi_b[p];
+      }
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = c0 + p * kWave + lane;
       const bool valid = i < i_end;
       int2 pr = make_int2(0, 0);
-      if (valid) pr = a.pairs[base + i];
+      if (valid) {
+        const int blk = lo_b[p];
+        pr = a.pairs[(size_t)blk * a.segsize + a.loff[(size_t)blk * a.nr + r] + (i - pre_r[blk])];
+      }
       gam[p] = __int_as_float(pr.y);             // 0 for the padding lanes: x = 0 keeps phi finite, gamma = 0 removes it
       sp_load_row<D>(a.x + (long)pr.x * a.Dreal, a.Dreal, valid, xq[p]);
       sp_load_row<OP>(a.g + (long)pr.x * a.O, a.O, valid, gq[p]);
@@ -1133,39 +1191,53 @@ int sparse_vjp_slices(const irbfn_net* net, int64_t B) {
   return sl < 1 ? 1 : (sl > 64 ? 64 : sl);
 }
 
-// workspace of the pair lists, in bytes (after the dense plan's buffers): wcnt, offs [nwv][nr]; tot [nr]; pairs [B * cap]
-size_t sparse_vjp_workspace_bytes(const irbfn_net* net, int64_t B) {
-  const size_t nwv = (size_t)((B + kWave - 1) / kWave);
+// workspace of the pair lists, in bytes: cnt, loff [nblk][nr]; pre [nr][nblk]; tot [nr]; pairs [nblk][NT * cap]
+struct SpWs {
+  size_t cnt, loff, pre, tot, pairs, total;
+  int nblk;
+};
+static SpWs sp_ws_layout(const irbfn_net* net, int64_t B) {
+  SpWs w;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  return 2 * al(nwv * net->n_ranges * 4) + al((size_t)net->n_ranges * 4) + al((size_t)B * net->sp_cap * 8);
+  w.nblk = (int)((B + kSpNT - 1) / kSpNT);
+  const size_t tab = al((size_t)w.nblk * net->n_ranges * 4);
+  size_t o = 0;
+  w.cnt = o; o += tab;
+  w.loff = o; o += tab;
+  w.pre = o; o += tab;
+  w.tot = o; o += al((size_t)net->n_ranges * 4);
+  w.pairs = o; o += al((size_t)w.nblk * kSpNT * net->sp_cap * 8);
+  w.total = o;
+  return w;
 }
+size_t sparse_vjp_workspace_bytes(const irbfn_net* net, int64_t B) { return sp_ws_layout(net, B).total; }
 
 // pair lists + K2r -> slab part[SL][V][Npad]; the caller runs the slab reduce and the bias sums
 int launch_vjp_sparse(irbfn_net* net, const float* x, const float* gout, int64_t B, void* spws, float* part, int SL, int Npad,
                       hipStream_t s) {
   if (!sparse_vjp_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
   const int nr = net->n_ranges;
-  const size_t nwv = (size_t)((B + kWave - 1) / kWave);
-  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const SpWs w = sp_ws_layout(net, B);
   char* base = static_cast<char*>(spws);
-  int* wcnt = reinterpret_cast<int*>(base);
-  int* offs = reinterpret_cast<int*>(base + al(nwv * nr * 4));
-  int* tot = reinterpret_cast<int*>(base + 2 * al(nwv * nr * 4));
-  int2* pairs = reinterpret_cast<int2*>(base + 2 * al(nwv * nr * 4) + al((size_t)nr * 4));
+  int* cnt = reinterpret_cast<int*>(base + w.cnt);
+  int* loff = reinterpret_cast<int*>(base + w.loff);
+  int* pre = reinterpret_cast<int*>(base + w.pre);
+  int* tot = reinterpret_cast<int*>(base + w.tot);
+  int2* pairs = reinterpret_cast<int2*>(base + w.pairs);
   SpPairArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.x = x; pa.img = net->sp_img; pa.B = (long)B; pa.Dreal = net->D; pa.nr = nr; pa.E = net->sp_E; pa.ns = net->nsplit;
-  pa.RS = net->sp_RS; pa.K = net->K; pa.cap = net->sp_cap; pa.nwv = (int)nwv; pa.wcnt = wcnt; pa.offs = offs; pa.tot = tot;
-  pa.pairs = pairs;
+  pa.RS = net->sp_RS; pa.K = net->K; pa.cap = net->sp_cap; pa.nblk = w.nblk; pa.cnt = cnt; pa.loff = loff; pa.pairs = pairs;
   const SpImg im = sp_img_layout(nr, net->sp_RS, net->sp_E, net->K);
   const size_t nr64 = ((size_t)nr + 63) & ~(size_t)63;
+  const size_t NW = kSpNT / kWave;
   const size_t lds = ((size_t)im.small + (size_t)net->sp_E * kSpNT + 9 * kSpNT + (size_t)((nr + 31) / 32) * kSpNT +
-                      2 * (kSpNT / kWave) * nr64 + nr + (size_t)(kSpNT / kWave) * nr + 8) * 4;
+                      2 * NW * nr64 + NW * nr64 + nr64 + NW + 8) * 4;
   if (lds > kSpMaxLds) return IRBFN_ERR_UNSUPPORTED;
-  const dim3 gridp((unsigned)((B + kSpNT - 1) / kSpNT));
-#define IRBFN_SPP(DV, FILLV)                                                                                         \
+  const dim3 gridp((unsigned)w.nblk);
+#define IRBFN_SPP(DV)                                                                                                \
   do {                                                                                                               \
-    auto k = sparse_pairs_kernel<DV, FILLV>;                                                                         \
+    auto k = sparse_pairs_kernel<DV>;                                                                                \
     static thread_local int attr_dev = -1;                                                                           \
     int dev = 0;                                                                                                     \
     IRBFN_HIP_CHECK(hipGetDevice(&dev));                                                                             \
@@ -1177,26 +1249,26 @@ int launch_vjp_sparse(irbfn_net* net, const float* x, const float* gout, int64_t
     hipLaunchKernelGGL(k, gridp, dim3(kSpNT), lds, s, pa);                                                           \
     IRBFN_HIP_CHECK(hipGetLastError());                                                                              \
   } while (0)
-#define IRBFN_SPP_D(FILLV)                                                                                           \
-  switch (net->DC) {                                                                                                 \
-    case 3: IRBFN_SPP(3, FILLV); break;                                                                              \
-    case 4: IRBFN_SPP(4, FILLV); break;                                                                              \
-    case 7: IRBFN_SPP(7, FILLV); break;                                                                              \
-    case 8: IRBFN_SPP(8, FILLV); break;                                                                              \
-    default: return IRBFN_ERR_UNSUPPORTED;                                                                           \
+  switch (net->DC) {
+    case 3: IRBFN_SPP(3); break;
+    case 4: IRBFN_SPP(4); break;
+    case 7: IRBFN_SPP(7); break;
+    case 8: IRBFN_SPP(8); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
   }
-  IRBFN_SPP_D(false)
-  hipLaunchKernelGGL(sparse_scan_kernel, dim3(nr), dim3(256), 0, s, wcnt, offs, tot, (int)nwv, nr);
-  IRBFN_HIP_CHECK(hipGetLastError());
-  IRBFN_SPP_D(true)
-#undef IRBFN_SPP_D
 #undef IRBFN_SPP
+  hipLaunchKernelGGL(sparse_scan_kernel, dim3(nr), dim3(256), 0, s, cnt, pre, tot, w.nblk, nr);
+  IRBFN_HIP_CHECK(hipGetLastError());
   SpVjpArgs va;
   memset(&va, 0, sizeof(va));
-  va.x = x; va.g = gout; va.rec = net->rec; va.sig2 = net->sig2; va.pairs = pairs; va.tot = tot; va.part = part;
+  va.x = x; va.g = gout; va.rec = net->rec; va.sig2 = net->sig2; va.pairs = pairs; va.tot = tot; va.pre = pre; va.loff = loff;
+  va.part = part;
   va.Dreal = net->D; va.O = net->O; va.K = net->K; va.nr = nr; va.S = net->S; va.Npad = Npad; va.SL = SL;
+  va.nblk = w.nblk; va.segsize = kSpNT * net->sp_cap;
+  va.nsteps = 0;
+  while ((1 << va.nsteps) < w.nblk) ++va.nsteps;  // halvings of [0, nblk) down to one block
   va.gscale = gauss_scale(net->basis);
-  const dim3 gridv(net->R, SL);               // every region gets its slab rows (zeros where no query is live)
+  const dim3 gridv(net->R, SL);                  // every region gets its slab rows (zeros where no query is live)
   const size_t ldsv = (size_t)net->K * (net->DC + 1 + net->OP) * 4;
   int rc;
   switch (net->DC) {

@@ -90,15 +90,49 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
   float lsum = 0.0f;
   for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long)gridDim.x * 256) {
     const float v0 = clipf(x[b * D + 0], VMIN, VMAX);       // :319
+    // the row's label and prediction in registers up front (short horizons: the reference's T = 5): the roll-outs below
+    // then run without a load in their dependency chain (one load per step: 30 serial round trips per row before)
+    constexpr bool REGS = TMAX <= 8;
+    float yr[REGS ? 2 * TMAX : 1], pr[REGS ? 2 * TMAX : 1], gr[REGS ? 2 * TMAX : 1];
+    if constexpr (REGS) {
+#pragma unroll
+      for (int o = 0; o < 2 * TMAX; ++o) {
+        yr[o] = o < O ? y[b * O + o] : 0.0f;
+        pr[o] = o < O ? yp[b * O + o] : 0.0f;
+        gr[o] = 0.0f;
+      }
+    }
+    auto lab = [&](int t, int half) -> float {             // control `t` of the label: a_t (half = 0) / sv_t (half = 1)
+      if constexpr (REGS) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 2 * TMAX; ++o) v = (o == half * T + t) ? yr[o] : v;
+        return v;
+      } else {
+        return y[b * O + half * T + t];
+      }
+    };
+    auto prd = [&](int t, int half) -> float {
+      if constexpr (REGS) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 2 * TMAX; ++o) v = (o == half * T + t) ? pr[o] : v;
+        return v;
+      } else {
+        return yp[b * O + half * T + t];
+      }
+    };
     float sa[5] = {0.0f, 0.0f, 0.0f, v0, 0.0f};
-    for (int t = 0; t < T; ++t) fullint_step(sa, y[b * O + t], y[b * O + T + t]);   // :329-347
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < T) fullint_step(sa, lab(t, 0), lab(t, 1));     // :329-347
     float sp[5] = {0.0f, 0.0f, 0.0f, v0, 0.0f};
     float pd[TMAX], pv[TMAX], pp[TMAX];                       // delta, v, yaw before step t
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
       if (t < T) {
         pd[t] = sp[2]; pv[t] = sp[3]; pp[t] = sp[4];
-        fullint_step(sp, yp[b * O + t], yp[b * O + T + t]);  // :356-374
+        fullint_step(sp, prd(t, 0), prd(t, 1));               // :356-374
       }
     }
     float lam[5];
@@ -108,11 +142,20 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
       lsum += fabsf(d) * inv_s;
       lam[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_s;    // d|.| = sign
     }
-    for (int o = 0; o < O; ++o) gy[b * O + o] = 0.0f;
+    if constexpr (!REGS)
+      for (int o = 0; o < O; ++o) gy[b * O + o] = 0.0f;
+    auto put = [&](int o_idx, float v) {
+      if constexpr (REGS) {
+#pragma unroll
+        for (int o = 0; o < 2 * TMAX; ++o) gr[o] = (o == o_idx) ? v : gr[o];
+      } else {
+        gy[b * O + o_idx] = v;
+      }
+    };
 #pragma unroll
     for (int t = TMAX - 1; t >= 0; --t) {                    // reverse sweep (oracle/hand_vjp.py: vjp_fullint)
       if (t < T) {
-        const float a = yp[b * O + t], dv = yp[b * O + T + t];
+        const float a = prd(t, 0), dv = prd(t, 1);
         const float dpre = pd[t] + dv * DT, vpre = pv[t] + a * DT;
         const float d1 = clipf(dpre, -SMAX, SMAX), v1 = clipf(vpre, VMIN, VMAX);
         const float md = clipgrad_t(dpre, -SMAX, SMAX, tie), mv = clipgrad_t(vpre, VMIN, VMAX, tie);
@@ -121,8 +164,8 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
         const float td = tan_fast(d1);
         const float Ld = lam[2] + lam[4] * (v1 / WB) * (1.0f + td * td) * DT;
         const float Lv = lam[3] + lam[4] * td * DT / WB;
-        gy[b * O + t] = mv * Lv * DT;
-        gy[b * O + T + t] = md * Ld * DT;
+        put(t, mv * Lv * DT);
+        put(T + t, md * Ld * DT);
         const float l2 = md * Ld;
         const float l3 = mv * Lv + DT * (lam[0] * cs + lam[1] * sn);
         const float l4 = lam[4] + DT * pv[t] * (-lam[0] * sn + lam[1] * cs);
@@ -130,10 +173,22 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
       }
     }
     const int cols[2] = {0, T};                               // y_predictions[:, [0, 5]]  (:387)
+#pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float d = yp[b * O + cols[k]] - y[b * O + cols[k]];
+      const float d = prd(0, k) - lab(0, k);                  // column k * T
       lsum += fabsf(d) * inv_y;
-      gy[b * O + cols[k]] += (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_y;
+      const float sgn = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_y;
+      if constexpr (REGS) {
+#pragma unroll
+        for (int o = 0; o < 2 * TMAX; ++o) gr[o] += (o == cols[k]) ? sgn : 0.0f;
+      } else {
+        gy[b * O + cols[k]] += sgn;
+      }
+    }
+    if constexpr (REGS) {
+#pragma unroll
+      for (int o = 0; o < 2 * TMAX; ++o)
+        if (o < O) gy[b * O + o] = gr[o];
     }
   }
   const float tot = block_sum_256(lsum, sm);
@@ -205,8 +260,13 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict_
 }
 
 // ---- optimiser: clip_by_global_norm + adam ----------------------------------------------------------
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+// Also hands the incremented step count to adam_clip_kernel through part[kRedBlocks] (the buffer holds kSeedBlocksMax
+// floats): every block of the Adam kernel reads THAT word, its thread (0, 0) stores it back to step[0] -- no block reads
+// step[0] there, so no separate "bump" launch is needed.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part,
+                                                             const int* __restrict__ step) {
   __shared__ float sm[256];
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(part)[kRedBlocks] = step[0] + 1;
   float v = 0.0f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) v += g[i] * g[i];
   const float tot = block_sum_256(v, sm);
@@ -218,13 +278,14 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 //   update = -lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps) ; t is the incremented count.
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long n,
-                                                        const int* __restrict__ step, const float* __restrict__ part,
+                                                        int* __restrict__ step, const float* __restrict__ part,
                                                         float lr, float b1, float b2, float eps, float max_norm) {
   __shared__ float sm[256];
   const float sq = block_sum_256(threadIdx.x < kRedBlocks ? part[threadIdx.x] : 0.0f, sm);   // same in every block
   const float gn = sqrtf(sq);
   const float scale = (max_norm > 0.0f && !(gn < max_norm)) ? max_norm / gn : 1.0f;
-  const int t = step[0] + 1;
+  const int t = reinterpret_cast<const int*>(part)[kRedBlocks];   // step[0] + 1, written by sqnorm_partial_kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = t;
   const float c1 = 1.0f - powf(b1, (float)t), c2 = 1.0f - powf(b2, (float)t);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * scale;
@@ -236,15 +297,20 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
   }
 }
 
-__global__ void bump_step_kernel(int* step) { step[0] = step[0] + 1; }
-
 }  // namespace irbfn
 
 using namespace irbfn;
 
 extern "C" {
 
-int irbfn_train_loss_partials(void) { return kRedBlocks; }
+int irbfn_train_loss_partials(void) { return kSeedBlocksMax; }
+
+// blocks of the loss / seed kernels: one row per thread (a second pass over the rows doubled the kernel: 18 -> 9 us at the
+// reference's batch of 80000), grid-stride beyond kSeedBlocksMax * 256 rows
+static int seed_blocks(int64_t B) {
+  const int64_t nb = (B + 255) / 256;
+  return nb < 1 ? 1 : (nb > kSeedBlocksMax ? kSeedBlocksMax : (int)nb);
+}
 
 int irbfn_train_seeds_oneint(const float* x_dev, const float* y_pred_dev, const float* y_dev,
                              const float* dyn_params_host, float clip_tie, float* gy_dev, float* loss_dev,
@@ -255,10 +321,10 @@ int irbfn_train_seeds_oneint(const float* x_dev, const float* y_pred_dev, const 
   DynParams dp;
   memcpy(dp.p, dyn_params_host, sizeof(dp.p));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(seeds_oneint_kernel, dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+  hipLaunchKernelGGL(seeds_oneint_kernel, dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                      partials_dev, (long)B, D, O, dp, clip_tie);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, kRedBlocks, loss_dev);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, seed_blocks(B), loss_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -272,13 +338,13 @@ int irbfn_train_seeds_fullint(const float* x_dev, const float* y_pred_dev, const
   if (!loss_dev || !partials_dev) return IRBFN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (T <= 8)
-    hipLaunchKernelGGL((seeds_fullint_kernel<8>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+    hipLaunchKernelGGL((seeds_fullint_kernel<8>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, clip_tie);
   else
-    hipLaunchKernelGGL((seeds_fullint_kernel<64>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+    hipLaunchKernelGGL((seeds_fullint_kernel<64>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, clip_tie);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, kRedBlocks, loss_dev);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, seed_blocks(B), loss_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -293,13 +359,13 @@ int irbfn_train_seeds_frenet_fullint(const float* x_dev, const float* y_pred_dev
   memcpy(dp.p, dyn_params_host, sizeof(dp.p));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (T <= 5)
-    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<5>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<5>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, dp, clip_tie);
   else
-    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<16>), dim3(kRedBlocks), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+    hipLaunchKernelGGL((seeds_frenet_fullint_kernel<16>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, dp, clip_tie);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, kRedBlocks, loss_dev);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials_dev, seed_blocks(B), loss_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }
@@ -310,15 +376,13 @@ int irbfn_adam_clip_step(float* params_dev, const float* grads_dev, float* m_dev
   if (n < 0 || !step_dev || !partials_dev) return IRBFN_ERR_BAD_ARG;
   if (n > 0 && (!params_dev || !grads_dev || !m_dev || !v_dev)) return IRBFN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(kRedBlocks), dim3(256), 0, s, grads_dev, (long)n, partials_dev);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(kRedBlocks), dim3(256), 0, s, grads_dev, (long)n, partials_dev, step_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params_dev, grads_dev, m_dev, v_dev,
                      (long)n, step_dev, partials_dev, lr, beta1, beta2, eps, max_grad_norm);
-  IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
   IRBFN_HIP_CHECK(hipGetLastError());
   return IRBFN_OK;
 }

@@ -107,10 +107,16 @@ class ClusterTrainState(TrainState):
         return self._views(self.m), self._views(self.v), int(self.step.item())
 
 
+def _fresh_loss(state: TrainState, torch):
+    """Every step writes its loss into a 1-element device buffer of its own (caching allocator: no launch), so the
+    tensor a step returns stays valid without a device-to-device copy per step."""
+    state.loss = torch.empty_like(state.loss)
+
+
 def _backward_and_update(state: TrainState, x, gy, torch, lib, **vjp_kw):
     """VJP -> [all-reduce] -> clip + Adam.  Returns the loss of the (global) batch, a 1-element device tensor."""
     state.net.vjp(state.params, x, gy, out=state.grads, **vjp_kw)
-    loss = state.loss.clone()
+    loss = state.loss            # a buffer of this step's own (see _fresh_loss): no copy, never overwritten later
     if distributed.is_dist() and torch.distributed.get_world_size() > 1:
         # every rank normalised its seeds and its loss by its LOCAL batch: weight both by B_local, sum over the
         # ranks in one all-reduce of the flat buffer, divide by the global batch (exact for unequal shards)
@@ -141,6 +147,7 @@ def train_step_oneint(state: TrainState, x, y, dyn_params, clip_tie: float = 0.5
     y_pred = state.net.apply(state.params, xd)
     gy = torch.empty_like(y_pred)
     keep, pp = _dyn(dyn_params)
+    _fresh_loss(state, torch)
     st = lib.irbfn_train_seeds_oneint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy), _ptr(state.loss),
                                       _ptr(state.partials), B, xd.shape[1], O, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_oneint")
@@ -157,6 +164,7 @@ def train_step_fullint(state: TrainState, x, y, clip_tie: float = 0.5) -> Tuple[
         raise ValueError("train_step_fullint needs y [B, out_features = 2T]")
     y_pred = state.net.apply(state.params, xd)
     gy = torch.empty_like(y_pred)
+    _fresh_loss(state, torch)
     st = lib.irbfn_train_seeds_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), float(clip_tie), _ptr(gy), _ptr(state.loss),
                                        _ptr(state.partials), B, xd.shape[1], O // 2, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_fullint")
@@ -176,6 +184,7 @@ def train_step_frenet_fullint(state: TrainState, x, y, dyn_params, clip_tie: flo
     y_pred = state.net.apply(state.params, xd)
     gy = torch.empty_like(y_pred)
     keep, pp = _dyn(dyn_params)
+    _fresh_loss(state, torch)
     st = lib.irbfn_train_seeds_frenet_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy),
                                               _ptr(state.loss), _ptr(state.partials), B, 8, O // 2, _stream_ptr(torch))
     _lib.check(st, "irbfn_train_seeds_frenet_fullint")
@@ -197,6 +206,7 @@ def train_step_fullint_withcluster(state: ClusterTrainState, x, y, cluster_ids, 
     gy, glogits = torch.empty_like(y_pred), torch.empty_like(logits)
     keep, pp = _dyn(dyn_params)
     stream = _stream_ptr(torch)
+    _fresh_loss(state, torch)
     st = lib.irbfn_train_seeds_frenet_fullint(_ptr(xd), _ptr(y_pred), _ptr(yd), pp, float(clip_tie), _ptr(gy),
                                               _ptr(state.loss), _ptr(state.partials), B, 8, O // 2, stream)
     _lib.check(st, "irbfn_train_seeds_frenet_fullint")

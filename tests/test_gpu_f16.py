@@ -130,14 +130,14 @@ def test_f16mfma_shapes_and_bases(gpu, D, K, O, basis):
 
 def test_f16mfma_not_used_where_ineligible(gpu):
     """Multi-region nets are not eligible: forcing K1h is refused (IRBFN_ERR_UNSUPPORTED -> ValueError), the
-    automatic choice keeps the gated float32 kernel."""
+    automatic choice is a float32 kernel of the multi-region family (the region-sparse K1r for this sparse gate)."""
     cfg, params, x, *_ = load_ckpt_fixture("dnmpc_128regions")
     net = WCRBFNet.from_config(cfg)
     xs = np.repeat(x.astype(np.float32), 4, axis=0)
     with pytest.raises(ValueError):
         _run(net, orc.cast_params(params, np.float32), xs)
     net.apply(orc.cast_params(params, np.float32), xs)
-    assert net.last_launch()["kernel"].startswith("rbf_fwd_qlane")
+    assert net.last_launch()["kernel"].startswith(("rbf_fwd_sparse", "rbf_fwd_qlane"))
     # NaN queries propagate (IEEE), other rows are unaffected
     cfg2, p2 = configs.model_card(2), configs.synth_params(2)
     net2 = WCRBFNet.from_config(cfg2)

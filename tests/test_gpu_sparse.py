@@ -223,3 +223,29 @@ def test_train_step_on_the_128_region_net_uses_the_sparse_kernels(gpu):
         res[name] = (losses, st.flat.clone())
     assert np.allclose(res["sparse"][0], res["dense"][0], rtol=2e-5)
     assert (res["sparse"][1] - res["dense"][1]).abs().max() <= 1e-4 * res["dense"][1].abs().max()
+
+
+def test_sparse_forward_large_batch_gathers_the_centre_table_from_global_memory(gpu):
+    """More workgroups than CUs: the kernel variant that leaves the centre table in global memory (three workgroups per CU)
+    is taken; same arithmetic in the same order as the LDS variant -> bit-identical rows, and the tick likewise."""
+    import torch
+    cfg, P, *_ = load_ckpt_fixture("dnmpc_128regions")
+    B = 70001
+    x = torch.from_numpy(_queries(cfg, B, seed=12)).cuda()
+    net = WCRBFNet.from_config(cfg)
+    net.set_options(fwd_kernel=_lib.FWD_K1R)
+    big = net.apply(P, x)
+    assert "GC=1" in net.last_launch()["kernel"]
+    small = net.apply(P, x[:3000].contiguous())
+    assert "GC=0" in net.last_launch()["kernel"]
+    assert torch.equal(big[:3000], small)
+    rows = np.arange(0, B, 97)
+    xr = x.cpu().numpy()[rows]
+    ref = orc.wcrbfnet_apply(cfg, orc.cast_params(P, np.float64), xr.astype(np.float64))
+    cancel, _ = _cancel(cfg, P, xr)
+    assert (np.abs(big.cpu().numpy()[rows] - ref) <= 1e-5 * np.abs(ref) + 3e-6 * cancel).all()
+    s0 = torch.from_numpy(configs.initial_state_from_query(x.cpu().numpy())).cuda()
+    ctrl, states = planner.plan_tick(net, P, x, None, s0, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    assert "GC=1" in net.last_launch()["kernel"] and "ROLL=1" in net.last_launch()["kernel"]
+    c2, s2 = planner.plan_tick(net, P, x[:3000].contiguous(), None, s0[:3000].contiguous(), configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
+    assert torch.equal(ctrl[:3000], c2) and torch.equal(states[:3000], s2) and torch.equal(ctrl, big)
