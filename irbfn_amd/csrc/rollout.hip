@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64 * kRegsWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
   }
   [[maybe_unused]] float coef[4];
   [[maybe_unused]] float slen = 0.0f;
+  [[maybe_unused]] float spc[2] = {0.0f, 1.0f};      // spiral: (sin, cos) of the current heading, carried step to step
   if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
     s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
     s[3] = clipf(q0[0], 0.0f, 7.0f);             // train_nmpc.py:319
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * kRegsWaves, TCH > 8 ? IRBFN_ROLL_MINW : 4) voi
             else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[t0 + tt], us[t0 + tt], a.dp);
             else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[t0 + tt], us[t0 + tt]);
             else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[t0 + tt], us[t0 + tt], a.dp);
-            else spiral_step(s, coef, slen, tg + t0 + tt, T);
+            else spiral_step(s, coef, slen, tg + t0 + tt, T, spc);
 #pragma unroll
             for (int i = 0; i < S; ++i) wr[tt * S + i] = s[i];
           }
@@ -390,6 +391,7 @@ __global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(co
   float s[S];
   [[maybe_unused]] float coef[4];
   [[maybe_unused]] float slen = 0.0f;
+  [[maybe_unused]] float spc[2] = {0.0f, 1.0f};      // spiral: (sin, cos) of the current heading, carried step to step
   if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
     s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
     s[3] = clipf(row[0], 0.0f, 7.0f);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(co
       else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ua[tt], us[tt], a.dp);
       else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ua[tt], us[tt]);
       else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ua[tt], us[tt], a.dp);
-      else spiral_step(s, coef, slen, t0 + tt, T);
+      else spiral_step(s, coef, slen, t0 + tt, T, spc);
 #pragma unroll
       for (int i = 0; i < S; ++i) mine[myC + tt * S + i] = s[i];
     }
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(64 * kRollWaves, 3) void rollout_fwd_lean_kernel(co
     else if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(s, ca, cs, a.dp);
     else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(s, ca, cs);
     else if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) frenet_step(s, ca, cs, a.dp);
-    else spiral_step(s, coef, slen, t, T);
+    else spiral_step(s, coef, slen, t, T, spc);
 #pragma unroll
     for (int i = 0; i < S; ++i) mine[fill + i] = s[i];
     fill += S;

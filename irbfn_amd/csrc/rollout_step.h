@@ -119,20 +119,31 @@ __device__ __forceinline__ void st_step(float (&s)[7], float accl_in, float sv_i
   const float ACCL = clipf(accl_in, -a_max, a_max);      // :46
   const float SV = clipf(sv_in, -sv_max, sv_max);        // :47
   float f0, f1, f4, f5, f6;
-  if (SELECT && V > 3.0f) {                              // :49-76
-    float sn, cs;
-    trig.sincos(PSI + BETA, sn, cs);
-    f0 = V * cs;
-    f1 = V * sn;
-    f4 = PSI_DOT;
+  if constexpr (SELECT) {
+    // lax.select(V > 3, f, f_ks) (:90) WITHOUT a branch.  The batch mixes fast and slow trajectories in every wave, so a
+    // branch ran both right-hand sides one after the other, each with its own trigonometry (191 us against 107 us for the
+    // kinematic scan at B = 262144, T = 50).  Both need cos / sin of ONE angle -- psi + beta (:50-51) or psi (:79-80) --
+    // so the angle is selected first and evaluated once (with the tan of the kinematic branch beside it: the lane pair of
+    // TrigPair shares the two evaluations); the few dozen flops of both branches follow as straight-line code and the
+    // results are selected.  Same expressions, same order: a lane gets the bits the branch gave it (an unselected
+    // PSI_DOT / V at V = 0 is inf / nan and is dropped by the select, as in the reference's own lax.select).
+    const bool dyn = V > 3.0f;
+    float sn, cs, tn;
+    trig.sincos_tan(dyn ? PSI + BETA : PSI, DELTA, s_max < 4194304.0f, sn, cs, tn);
+    f0 = V * cs;                                           // :50 / :79
+    f1 = V * sn;                                           // :51 / :80
     const float glr = g * lr - ACCL * h, glf = g * lf + ACCL * h;
-    f5 = ((mu * m) / (I * (lf + lr))) *
-         (lf * C_Sf * glr * DELTA + (lr * C_Sr * glf - lf * C_Sf * glr) * BETA -
-          (lf * lf * C_Sf * glr + lr * lr * C_Sr * glf) * (PSI_DOT / V));
-    f6 = (mu / (V * (lr + lf))) *
-             (C_Sf * glr * DELTA - (C_Sr * glf + C_Sf * glr) * BETA +
-              (C_Sr * glf * lr - C_Sf * glr * lf) * (PSI_DOT / V)) -
-         PSI_DOT;
+    const float pv = PSI_DOT / V;
+    const float f5d = ((mu * m) / (I * (lf + lr))) *
+                      (lf * C_Sf * glr * DELTA + (lr * C_Sr * glf - lf * C_Sf * glr) * BETA -
+                       (lf * lf * C_Sf * glr + lr * lr * C_Sr * glf) * pv);                      // :54-63
+    const float f6d = (mu / (V * (lr + lf))) *
+                          (C_Sf * glr * DELTA - (C_Sr * glf + C_Sf * glr) * BETA +
+                           (C_Sr * glf * lr - C_Sf * glr * lf) * pv) -
+                      PSI_DOT;                                                                    // :64-76
+    f4 = dyn ? PSI_DOT : fdiv_fast(V, lr + lf) * tn;       // :53 / :84
+    f5 = dyn ? f5d : 0.0f;
+    f6 = dyn ? f6d : 0.0f;
   } else {                                               // :78-88
     float sn, cs, tn;
     trig.sincos_tan(PSI, DELTA, s_max < 4194304.0f, sn, cs, tn);
@@ -203,30 +214,47 @@ __device__ __forceinline__ void spiral_coefs(const float (&q)[5], float (&c)[4])
   c[3] = c[3] / (s * s * s);                             // :28
 }
 
-// integrate_one_step (planner_utils.py:44-59); st = [x, y, theta, kappa, dx, dy]; i = 0-based sample
-__device__ __forceinline__ void spiral_step(float (&st)[6], const float (&c)[4], float s, int i, int N) {
+// integrate_one_step (planner_utils.py:44-59); st = [x, y, theta, kappa, dx, dy]; i = 0-based sample.
+// sc: (sin, cos) of st[2] on entry, of the new theta on exit.  The step needs cos / sin of the new AND the old heading
+// (:47-54); the old one is the previous step's new one, so a caller that walks the samples in order carries the pair instead
+// of evaluating it again (sin, cos of theta = 0, the scan's initial heading, are exactly (0, 1)): same bits, half the
+// trigonometry.
+// Divisions: the reference divides by (j + 1), by k and by 2 (:36-41, :47-54).  IEEE division sequences (~12 instructions
+// each, ten per sample) made the spiral kernels compute-bound (forward 2.3, VJP 0.7-1.0 TB/s at N = 100); here: exact
+// constants' reciprocals for (j + 1) and 2 (<= 1 ulp each), reciprocal + one correction step for k and N - 1 (fdiv_fast,
+// <= 1 ulp).  Results move by a few ulp against the float32 restatement; the tests hold them to 1e-5 of the float64 one.
+__device__ __forceinline__ void spiral_step(float (&st)[6], const float (&c)[4], float s, int i, int N, float (&sc)[2]) {
 #pragma clang fp contract(off)   // same mul/add sequence in every kernel that inlines this (fused == stand-alone)
-  const float sk = (i < N - 1) ? s * ((float)i / (float)(N - 1)) : s;      // jnp.linspace(0, s, N) :71
+  const float sk = (i < N - 1) ? s * fdiv_fast((float)i, (float)(N - 1)) : s;   // jnp.linspace(0, s, N) :71
   const float k = (float)(i + 1);                                          // :72
+  const float rk = fdiv_fast(1.0f, k);
+  const float rj[4] = {1.0f, 0.5f, 1.0f / 3.0f, 0.25f};
   float kap = 0.0f, th = 0.0f, pw = 1.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                                            // :32-41
     const float temp = c[j] * pw;
     kap = kap + temp;
-    th = th + temp * sk / (float)(j + 1);
+    th = th + temp * sk * rj[j];
     pw = pw * sk;
   }
-  float s_new, c_new, s_old, c_old;
+  float s_new, c_new;
+  const float s_old = sc[0], c_old = sc[1];
   sincos_fast(th, s_new, c_new);
-  sincos_fast(st[2], s_old, c_old);
-  const float dx = st[4] * (1.0f - 1.0f / k) + (c_new + c_old) / 2.0f / k;   // :47-50
-  const float dy = st[5] * (1.0f - 1.0f / k) + (s_new + s_old) / 2.0f / k;   // :51-54
+  const float dx = st[4] * (1.0f - rk) + (c_new + c_old) * 0.5f * rk;      // :47-50
+  const float dy = st[5] * (1.0f - rk) + (s_new + s_old) * 0.5f * rk;      // :51-54
   st[0] = sk * dx;
   st[1] = sk * dy;
   st[2] = th;
   st[3] = kap;
   st[4] = dx;
   st[5] = dy;
+  sc[0] = s_new;
+  sc[1] = c_new;
+}
+__device__ __forceinline__ void spiral_step(float (&st)[6], const float (&c)[4], float s, int i, int N) {
+  float sc[2];
+  sincos_fast(st[2], sc[0], sc[1]);
+  spiral_step(st, c, s, i, N, sc);
 }
 
 }  // namespace irbfn

@@ -236,6 +236,135 @@ __global__ __launch_bounds__(64) void rollout_vjp_spiral(const RollVjpArgs a) {
   grow[4] = g_s;
 }
 
+// ---- cubic spiral, staged (N <= 256) -----------------------------------------------------------------------------------
+// The kernel above reads every seed as a per-lane dword at a stride of N * 24 bytes and parks theta / dx / dy of all N
+// samples in LDS (measured 0.75 TB/s at B = 262144, N = 100).  Here one wave owns 64 consecutive paths -- their seeds are ONE
+// contiguous block of HBM -- and walks the samples in chunks of G = 8, last chunk first:
+//  * the chunk's seeds (64 rows x 48 floats) are read by the whole wave as consecutive dwords (256 contiguous bytes per
+//    instruction, runs of 192 bytes per row) into an LDS tile of odd pitch and read back per row without bank conflicts;
+//  * no park of all samples: the forward pass keeps a checkpoint (theta, dx, dy before the chunk: 3 floats) per chunk in LDS,
+//    the reverse pass re-runs one chunk from its checkpoint into registers -- the forward's own values, same step function --
+//    and sweeps it backwards with the adjoint of the kernel above.
+constexpr int kSpiralG = 8;
+constexpr int kSpiralPitch = kSpiralG * 6 + 1;     // odd
+__global__ __launch_bounds__(64) void rollout_vjp_spiral_staged(const RollVjpArgs a) {
+  extern __shared__ float lds[];
+  constexpr int G = kSpiralG, PITCH = kSpiralPitch;
+  const int lane = threadIdx.x;
+  const long b0 = (long)blockIdx.x * kWave;
+  const long left = a.B - b0;
+  const int nvalid = left < kWave ? (int)left : kWave;
+  const int N = a.T;
+  const int nch = (N + G - 1) / G;
+  float* tile = lds;                             // [64][PITCH]
+  float* ck = lds + kWave * PITCH;               // [nch][3][64]
+  const long b = b0 + (lane < nvalid ? lane : nvalid - 1);
+  const float* row = a.x0u + b * 5;
+  float q[5], c[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) q[i] = row[i];
+  spiral_coefs(q, c);
+  const float slen = q[4];
+  {                                              // forward pass: checkpoints only
+    float st[6] = {0.0f, 0.0f, 0.0f, c[0], 0.0f, 0.0f};
+    float sc[2] = {0.0f, 1.0f};
+    for (int i = 0; i < N; ++i) {
+      if (i % G == 0) {
+        const int g = i / G;
+        ck[(g * 3 + 0) * kWave + lane] = st[2];
+        ck[(g * 3 + 1) * kWave + lane] = st[4];
+        ck[(g * 3 + 2) * kWave + lane] = st[5];
+      }
+      spiral_step(st, c, slen, i, N, sc);
+    }
+  }
+  const float* gs_tile = a.gstates + b0 * (long)N * 6;
+  const long rs = (long)N * 6;
+  float gc[4] = {0, 0, 0, 0};
+  float g_s = 0.0f, ldx = 0.0f, ldy = 0.0f, lth = 0.0f;
+#pragma unroll 1
+  for (int g = nch - 1; g >= 0; --g) {
+    const int i0 = g * G;
+    const int n = (N - i0) < G ? (N - i0) : G;
+    const int nf = n * 6;
+    // the chunk's seeds: consecutive lanes = consecutive floats of a row's segment
+    const float rnf = 1.0f / (float)nf;           // idx < 64 * 48: (idx + 0.5) / nf in float32 floors to the exact quotient
+    for (int idx = lane; idx < nvalid * nf; idx += kWave) {
+      const int r = (int)(((float)idx + 0.5f) * rnf), j = idx - r * nf;
+      tile[r * PITCH + j] = gs_tile[r * rs + (long)i0 * 6 + j];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // re-run the chunk from its checkpoint
+    float st[6] = {0.0f, 0.0f, ck[(g * 3 + 0) * kWave + lane], 0.0f, ck[(g * 3 + 1) * kWave + lane], ck[(g * 3 + 2) * kWave + lane]};
+    // parked per sample: sin / cos of its heading and of the previous one (the step's own evaluations: the adjoint below
+    // needs no trigonometry of its own -- four ocml sinf / cosf calls per sample made this kernel compute-bound), dx, dy
+    float psn[G], pcs[G], psp[G], pcp[G], pdx[G], pdy[G];
+    float sc[2];
+    sincos_fast(st[2], sc[0], sc[1]);
+#pragma unroll
+    for (int tt = 0; tt < G; ++tt) {
+      psp[tt] = sc[0]; pcp[tt] = sc[1];
+      if (tt < n) spiral_step(st, c, slen, i0 + tt, N, sc);
+      psn[tt] = sc[0]; pcs[tt] = sc[1]; pdx[tt] = st[4]; pdy[tt] = st[5];
+    }
+    const float* mine = tile + (lane < nvalid ? lane : nvalid - 1) * PITCH;
+#pragma unroll
+    for (int tt = G - 1; tt >= 0; --tt) {
+      if (tt < n) {
+        const int i = i0 + tt;
+        const float tau = (i < N - 1) ? fdiv_fast((float)i, (float)(N - 1)) : 1.0f;    // as spiral_step
+        const float sk = (i < N - 1) ? slen * tau : slen;
+        const float k = (float)(i + 1);
+        const float rk = fdiv_fast(1.0f, k);
+        const float dx = pdx[tt], dy = pdy[tt];
+        const float gx = mine[tt * 6 + 0], gy = mine[tt * 6 + 1], gth = mine[tt * 6 + 2], gka = mine[tt * 6 + 3],
+                    gdx = mine[tt * 6 + 4], gdy = mine[tt * 6 + 5];
+        const float Gdx = gdx + ldx + sk * gx;
+        const float Gdy = gdy + ldy + sk * gy;
+        float gsk = gx * dx + gy * dy;
+        const float Gth = gth + lth + (Gdx * (-psn[tt]) + Gdy * pcs[tt]) * (0.5f * rk);
+        lth = (Gdx * (-psp[tt]) + Gdy * pcp[tt]) * (0.5f * rk);     // sample 0: previous heading 0 -> (sin, cos) = (0, 1)
+        ldx = Gdx * (1.0f - rk);
+        ldy = Gdy * (1.0f - rk);
+        const float rj[4] = {1.0f, 0.5f, 1.0f / 3.0f, 0.25f};
+        float pw = 1.0f, kap = 0.0f, dkap = 0.0f, pwm1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gc[j] += Gth * (pw * sk) * rj[j] + gka * pw;
+          kap += c[j] * pw;
+          dkap += (float)j * c[j] * pwm1;
+          pwm1 = pw;
+          pw = pw * sk;
+        }
+        gsk += Gth * kap + gka * dkap;
+        g_s += gsk * tau;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();               // the tile is overwritten by the next chunk
+  }
+  const float PM[4][4] = {{1.0f, 0.0f, 0.0f, 0.0f},
+                          {-11.0f / 2, 9.0f, -9.0f / 2, 1.0f},
+                          {9.0f, -45.0f / 2, 18.0f, -9.0f / 2},
+                          {-9.0f / 2, 27.0f / 2, -27.0f / 2, 9.0f / 2}};
+  float inv = 1.0f;
+  float gq[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gq[m] += gc[r] * PM[r][m] * inv;
+    g_s += -(float)r * c[r] / slen * gc[r];
+    inv = inv / slen;
+  }
+  if (lane < nvalid) {
+    float* grow = a.gx0u + (b0 + lane) * 5;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) grow[m] = gq[m];
+    grow[4] = g_s;
+  }
+}
+
 // ---- K4: the same reverse sweeps with the memory machinery of the forward roll-out (T <= 50) ---------------------
 // The kernels above touch HBM through per-lane strided dwords (measured 0.5-0.9 TB/s at T = 50).  Here:
 //  * input rows: whole-tile LDS-DMA, the 2T controls of a trajectory live in registers (as in rollout.hip);
@@ -536,6 +665,12 @@ int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const fl
     else if (mode == IRBFN_ROLLOUT_FULLINT) rc = launch_vjp_regs<IRBFN_ROLLOUT_FULLINT>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
     else if (mode == IRBFN_ROLLOUT_FRENET_LS) rc = launch_vjp_regs<IRBFN_ROLLOUT_FRENET_LS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
+  if (mode == IRBFN_ROLLOUT_SPIRAL && T >= 1 && T <= 256) {          // 37 KB of LDS at N = 256
+    const size_t ldss = ((size_t)kWave * kSpiralPitch + (size_t)((T + kSpiralG - 1) / kSpiralG) * 3 * kWave) * sizeof(float);
+    hipLaunchKernelGGL(rollout_vjp_spiral_staged, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), ldss, s, a);
+    IRBFN_HIP_CHECK(hipGetLastError());
+    return IRBFN_OK;
   }
   int ns;
   switch (mode) {
