@@ -240,15 +240,17 @@ def forward_roofline(launch, B, N, D, O, kern_s):
     flops = B * N * (3 * D + 2 + 2 * O)                          # per pair 3D + 2 + 2O
     abytes = 4 * (B * D + N * D + N + N * O + O + B * O)         # every tensor touched once
     traffic, traffic_src = None, "none measured for this build (run tools/measure_traffic.py on the GPU box)"
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):      # newest round first
         rec = json.load(open(tpath)).get(launch["kernel"])
+        tname = "profiles/" + os.path.basename(tpath)
         if rec and rec.get("fingerprint") == kernel_fingerprint() and rec.get("grid") == launch["grid"]:
             traffic = rec["bytes"]
-            traffic_src = ("profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+            traffic_src = (f"{tname}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
                            "command, per launch; source fingerprint and launch geometry match this build")
+            break
         elif rec:
-            traffic_src = "profiles/r02_traffic.json is stale (kernel sources or launch geometry changed since it was measured)"
+            traffic_src = f"{tname} is stale (kernel sources or launch geometry changed since it was measured)"
     # the kernel's work by execution unit: the Phi x W products run on the f16 matrix cores as 3 f16 products per
     # f32 product (ph*wh, pl*wh, ph*wl), the outputs padded to one 16-wide tile; the rest is f32 VALU + 1 transcendental
     valu_flops = B * N * (3 * D + 2)
@@ -526,6 +528,14 @@ def single_gpu_extras(net, params, x, configs, torch):
         tt_ = _time(lambda: nt(xt_), 30, torch)
         trained[run] = {"us": tt_ * 1e6, "evals_per_s": 65536 / tt_, "regions": cfg_t["num_regions"],
                         "centres": cfg_t["num_regions"] * cfg_t["num_kernels"], "kernel": nt.last_launch()["kernel"]}
+        if cfg_t["num_regions"] > 1:
+            # the dense gated kernel on the same net (what the reference's model.py:187-193 evaluates: every region for every
+            # query), beside the automatic choice above (region-sparse K1r where the gate is sparse)
+            nt.set_options(fwd_kernel=_lib.FWD_K1)
+            td_ = _time(lambda: nt(xt_), 30, torch)
+            nt.set_options(fwd_kernel=_lib.FWD_AUTO)
+            trained[run]["dense_K1_us"] = td_ * 1e6
+            trained[run]["live_regions_per_query"] = float((nt.gate(xt_) != 0).sum(dim=1).float().mean().item())
         if cfg_t["out_features"] == 10 and cfg_t["in_features"] == 7:
             # the reference's training step at its own batch size (batch_size: 80000 in scripts/configs/*.yaml):
             # train_step_fullint = forward, loss seeds through the 5-step bicycle, parameter VJP, clip + Adam
@@ -537,6 +547,11 @@ def single_gpu_extras(net, params, x, configs, torch):
                 st_box[0], _ = train.train_step_fullint(st_box[0], xb, yb)
             ts_ = _time(_step, 20, torch)
             trained[run]["train_step_fullint_B80000"] = {"us": ts_ * 1e6, "evals_per_s": Bt_ / ts_}
+            if cfg_t["num_regions"] > 1:
+                nt.set_options(fwd_kernel=_lib.FWD_K1, vjp_kernel=_lib.VJP_K2)
+                st_box[0] = train.TrainState.create(nt, pt, lr=1e-3, max_grad_norm=1.0)
+                trained[run]["train_step_fullint_B80000"]["dense_K1_K2_us"] = _time(_step, 20, torch) * 1e6
+                nt.set_options(fwd_kernel=_lib.FWD_AUTO, vjp_kernel=_lib.VJP_AUTO)
             del xb, yb, st_box
         del xt_, nt
     out["reference_trained_checkpoints_forward_B65536"] = trained

@@ -2,7 +2,7 @@
     python tools/measure_traffic.py
 Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md) of
 `python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras`; per-launch means of the headline kernel ->
-profiles/r02_traffic.json, stamped with the kernel-source fingerprint and the launch geometry (bench.py ignores the
+profiles/<tag>_traffic.json (tag = argv[1], default r03), stamped with the kernel-source fingerprint and the launch geometry (bench.py ignores the
 record when either has changed).  FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3.  The forward reads
 dword-coalesced rows (not 16-byte-per-lane streams), for which the guide's x2 FETCH_SIZE correction is not
 calibrated: the value is stored uncorrected and the note says so."""
@@ -58,9 +58,10 @@ def main():
     for k in list(fetch):
         if k.split("<")[0].split("::")[-1] == lib_name.split("<")[0]:
             rec[lib_name] = dict(rec[k], profiler_name=k)
-    json.dump(rec, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=2)
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=2)
     # gpurun brings back gpurun_out/ only: copy the record from there into profiles/ after the call
-    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_traffic.json"), "w"), indent=2)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json"), "w"), indent=2)
     print(json.dumps(rec, indent=2))
 
 
