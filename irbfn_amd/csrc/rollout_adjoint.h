@@ -25,9 +25,11 @@ __device__ __forceinline__ void vjp_park(const float* s, float* p) {
 }
 
 // one reverse step: lam already holds the seeds of this step's output state; returns d/d(a_t), d/d(sv_t)
-template <int MODE>
+// Trig: how the step gets sin / cos of the heading and tan of the steering angle (rollout_step.h: TrigDirect, or the lane pair
+// of rollout_pair.h -- same values bit for bit)
+template <int MODE, typename Trig = TrigDirect>
 __device__ __forceinline__ void vjp_back_step(const float* p, float a_in, float sv_in, float* lam, float cur, float tie,
-                                              const DynParams& dp, float& ga, float& gsv) {
+                                              const DynParams& dp, float& ga, float& gsv, const Trig trig = Trig()) {
   if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) {
     const float lf = dp.p[3], lr = dp.p[4], dt = dp.p[8], sv_max = dp.p[9], a_max = dp.p[10], s_max = dp.p[11], v_max = dp.p[12];
     const float Lw = lr + lf;
@@ -36,7 +38,7 @@ __device__ __forceinline__ void vjp_back_step(const float* p, float a_in, float 
     const float md = clipgrad(d_raw, -s_max, s_max, tie), mv = clipgrad(v_raw, -v_max, v_max, tie);
     const float ma = clipgrad(a_in, -a_max, a_max, tie), ms = clipgrad(sv_in, -sv_max, sv_max, tie);
     float cp, sp, td;
-    TrigDirect().sincos_tan(psi, DELTA, s_max < 4194304.0f, sp, cp, td);
+    trig.sincos_tan(psi, DELTA, s_max < 4194304.0f, sp, cp, td);
     ga = ma * dt * lam[3];
     gsv = ms * dt * lam[2];
     const float l2 = lam[2] + md * lam[4] * (V / Lw) * (1.0f + td * td) * dt;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void vjp_back_step(const float* p, float a_in, float 
     const float d1 = clipf(dpre, -SMAX, SMAX), v1 = clipf(vpre, VMIN, VMAX);
     const float md = clipgrad(dpre, -SMAX, SMAX, tie), mv = clipgrad(vpre, VMIN, VMAX, tie);
     float cp, sp, td;
-    TrigDirect().sincos_tan(psi, d1, true, sp, cp, td);
+    trig.sincos_tan(psi, d1, true, sp, cp, td);
     const float Ld = lam[2] + lam[4] * (v1 / WB) * (1.0f + td * td) * DT;   // cotangent on delta'
     const float Lv = lam[3] + lam[4] * td * DT / WB;                        // cotangent on v'
     ga = mv * Lv * DT;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void vjp_back_step(const float* p, float a_in, float 
     const float md = clipgrad(d_raw, -s_max, s_max, tie);
     const float ma = clipgrad(a_in, -a_max, a_max, tie), ms = clipgrad(sv_in, -sv_max, sv_max, tie);
     float ce, se, td;
-    TrigDirect().sincos_tan(epsi, dc, s_max < 4194304.0f, se, ce, td);
+    trig.sincos_tan(epsi, dc, s_max < 4194304.0f, se, ce, td);
     const float den = 1.0f - ey * cur;
     const float d0 = vx * ce / den;
     const float A = lam[0] * dt - lam[6] * dt * cur;      // total cotangent on d0

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "rollout_step.h"
 #include "rollout_adjoint.h"
+#include "rollout_pair.h"
 
 namespace irbfn {
 
@@ -630,6 +631,291 @@ __global__ __launch_bounds__(64 * kVjpWaves, 2) void rollout_vjp_regs_kernel(con
   }
 }
 
+// ---- K4p: the same kernel with TWO LANES PER TRAJECTORY (as K3p of the forward, rollout_pair.h) ----------------------
+// MEASURED AND NOT TAKEN (round 3, profiles/r03_rollout_vjp_pair_lanes.txt; build with -DIRBFN_VJP_PAIR=1 to A/B, results
+// identical to K4 in every test): B = 262144, T = 50: ST kinematic 205.6 vs 212.6 us, inline bicycle 176.5 vs 138.0 us, Frenet
+// 268.2 vs 259.7 us.  Three waves per SIMD instead of two, but twice the waves and the same dependent chain per wave: K4 is
+// bound by the serial latency of a wave's three 50-step passes times the rounds of waves per SIMD, which pairing lanes does not
+// shorten.
+// K4 keeps the 2T controls of a trajectory in one lane's registers (100 at T = 50): 243 VGPRs, two waves per SIMD, and what
+// remains is one wave's serial latency.  Here a trajectory sits on a lane pair: the even lane holds the acceleration knots, the
+// odd lane the steering-rate knots (50 registers each; a step reads both by DPP), the step's trigonometry runs once per pair
+// (TrigPair: even lane sin / cos of the heading, odd lane tan of the steering angle, swapped by DPP -- the same values bit for
+// bit), everything else is evaluated by both lanes from the same operands; the control gradients replace the controls in
+// place, each lane its own stream.  ~145 VGPRs -> three waves per SIMD, 32 trajectories per wave, half the LDS per wave.
+constexpr int kVjpPairRows = 32;
+template <int MODE, int TCH>
+__global__ __launch_bounds__(64 * kVjpWaves, 3) void rollout_vjp_pair_kernel(const RollVjp2Args a) {
+  extern __shared__ float lds[];
+  constexpr int S = VjpTraits<MODE>::S, S0 = VjpTraits<MODE>::S0, NP = VjpTraits<MODE>::NP;
+  constexpr int G = vjp_group(TCH), NG = TCH / G;
+  constexpr int PITCH = vjp_pitch(S, G);
+  constexpr int NPC = vjp_pieces(S, G);          // 16-byte pieces of a row's aligned seed chunk
+  constexpr int RPP = kVjpRPP;
+  constexpr int R = kVjpPairRows;
+  constexpr int NRQ = (R * NPC + kWave - 1) / kWave;     // DMA instructions per seed request
+  static_assert(TCH % G == 0, "whole groups");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int odd = lane & 1, prow = lane >> 1;
+  const long b0 = ((long)blockIdx.x * kVjpWaves + wave) * R;
+  if (b0 >= a.B) return;
+  const long left = a.B - b0;
+  const int nvalid = left < R ? (int)left : R;
+  const int T = a.T, L = a.L;
+  float* tile = lds + (size_t)wave * a.wlds;
+  auto lds_drain = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const bool dma = nvalid == R && a.dma_ok;
+  const TrigPair trig{odd};
+
+  // ---- prologue: my row -> registers (each lane ONE control stream) -------------------------------------------------
+  float q0[S0], ctl[TCH];
+#pragma unroll
+  for (int t = 0; t < TCH; ++t) ctl[t] = 0.0f;
+  if (dma) {
+#pragma unroll 1
+    for (int p = 0; p < R / RPP; ++p) {
+      const float* src = a.x0u + (b0 + (long)p * RPP) * L;
+      const int nf = RPP * L;
+      for (int v = lane * 4; v < nf; v += 256)
+        __builtin_amdgcn_global_load_lds((vgptr_t)(src + v), (vlptr_t)(tile + (v - lane * 4)), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if ((prow / RPP) == p) {
+        const float* rr = tile + (prow % RPP) * L;
+#pragma unroll
+        for (int i = 0; i < S0; ++i) q0[i] = rr[i];
+        const float* cr = rr + S0 + (odd ? T : 0);
+#pragma unroll
+        for (int t = 0; t < TCH; ++t) ctl[t] = cr[t];          // slots t >= T are never used (they stay inside the tile)
+      }
+      lds_drain();
+    }
+  } else {
+    const float* row = a.x0u + (b0 + (prow < nvalid ? prow : nvalid - 1)) * L;
+#pragma unroll
+    for (int i = 0; i < S0; ++i) q0[i] = row[i];
+#pragma unroll
+    for (int t = 0; t < TCH; ++t)
+      if (t < T) ctl[t] = row[S0 + (odd ? T : 0) + t];
+  }
+  float s[S];
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) {
+    s[0] = 0.0f; s[1] = 0.0f; s[2] = 0.0f; s[4] = 0.0f;
+    s[3] = clipf(q0[0], 0.0f, 7.0f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < S; ++i) s[i] = q0[i];
+  }
+  [[maybe_unused]] float cur = 0.0f;
+  if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) cur = s[7];
+  auto knots = [&](float c, float& ua, float& us) {          // the pair's two knots of one step: even lane's, odd lane's
+    const int cv = __builtin_bit_cast(int, c);
+    ua = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(cv, 0xA0, 0xF, 0xF, true));
+    us = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(cv, 0xF5, 0xF, 0xF, true));
+  };
+  auto fwd = [&](float* st, float ua, float us) {
+    if constexpr (MODE == IRBFN_ROLLOUT_ST_KS) st_step<false>(*reinterpret_cast<float(*)[7]>(st), ua, us, a.dp, trig);
+    else if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) fullint_step(*reinterpret_cast<float(*)[5]>(st), ua, us, trig);
+    else frenet_step(*reinterpret_cast<float(*)[8]>(st), ua, us, a.dp, trig);
+  };
+
+  const float* gs_tile = a.gstates + b0 * (long)T * S;
+  const long rs = (long)T * S;
+  const int g4 = (int)((reinterpret_cast<uintptr_t>(gs_tile) >> 2) & 3);
+  float* tile2 = tile + R * PITCH;
+  auto request = [&](int gq, float* dst) {       // seeds of group gq -> dst (asynchronous; retired by vmcnt)
+    const int tq = gq * G;
+    const int nq = (T - tq) < G ? (T - tq) : G;
+#pragma unroll
+    for (int j = 0; j < NRQ; ++j) {
+      const int idx = j * kWave + lane;
+      const int r = idx / NPC, part = idx - r * NPC;
+      const int C = (g4 + (int)((r * rs + (long)tq * S) & 3)) & 3;
+      const float* src = gs_tile + r * rs + (long)tq * S - C + 4 * part;        // 16-byte aligned, inside the tile
+      if (idx < R * NPC && 4 * part < C + nq * S)
+        __builtin_amdgcn_global_load_lds((vgptr_t)src, (vlptr_t)(dst + j * 256), 16, 0, 0);
+    }
+  };
+  const int g_last = (T - 1) / G;                // the last group with steps
+  int cbuf = 0;
+  if (dma) request(g_last, tile);                // in flight during the whole forward pass
+
+  // ---- pass 1: forward, one checkpoint per group; arrays rotate DOWN circularly (static register indices)
+  float ck[NG][NP];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ck[g][i] = 0.0f;
+#pragma unroll 1
+  for (int gI = 0; gI < NG; ++gI) {
+    {
+      float pk[NP];
+      vjp_park<MODE>(s, pk);
+#pragma unroll
+      for (int g = 0; g + 1 < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) ck[g][i] = ck[g + 1][i];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ck[NG - 1][i] = pk[i];
+    }
+#pragma unroll
+    for (int tt = 0; tt < G; ++tt) {
+      if (gI * G + tt < T) {
+        float ua, us;
+        knots(ctl[tt], ua, us);
+        fwd(s, ua, us);
+      }
+    }
+    if constexpr (NG > 1) {
+      float tc[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) tc[i] = ctl[i];
+#pragma unroll
+      for (int i = 0; i + G < TCH; ++i) ctl[i] = ctl[i + G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) ctl[TCH - G + i] = tc[i];
+    }
+  }
+
+  // ---- pass 2: segments in reverse; the group's controls sit at [TCH - G, TCH) ---------------------------------
+  float lam[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) lam[i] = 0.0f;
+#pragma unroll 1
+  for (int gI = NG - 1; gI >= 0; --gI) {
+    const int t0 = gI * G;
+    if (t0 < T) {                                // wave-uniform
+      const int n = (T - t0) < G ? (T - t0) : G;
+      float* cur_tile = cbuf ? tile2 : tile;
+      const float* mine = cur_tile + prow * PITCH;
+      const int myC = (g4 + (int)((prow * rs + (long)t0 * S) & 3)) & 3;
+      if (dma) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this group's seeds have landed
+        __builtin_amdgcn_wave_barrier();
+        if (gI > 0) request(gI - 1, cbuf ? tile : tile2);    // the other tile was last read two groups ago
+      } else {
+        const float* src = gs_tile + (prow < nvalid ? prow : nvalid - 1) * rs + (long)t0 * S;
+        float* d = cur_tile + prow * PITCH + myC;
+        for (int i = odd; i < n * S; i += 2) d[i] = src[i];
+      }
+      cbuf ^= 1;
+      lds_drain();
+      float ss[S], park[G][NP], pk[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) pk[i] = ck[NG - 1][i];
+#pragma unroll
+      for (int i = 0; i < S; ++i) ss[i] = 0.0f;
+      if constexpr (MODE == IRBFN_ROLLOUT_FRENET_LS) { ss[1] = pk[0]; ss[2] = pk[1]; ss[3] = pk[2]; ss[6] = pk[3]; ss[7] = cur; }
+      else { ss[2] = pk[0]; ss[3] = pk[1]; ss[4] = pk[2]; }
+#pragma unroll
+      for (int tt = 0; tt < G; ++tt) {
+        vjp_park<MODE>(ss, park[tt]);
+        if (tt < n) {
+          float ua, us;
+          knots(ctl[TCH - G + tt], ua, us);
+          fwd(ss, ua, us);
+        }
+      }
+#pragma unroll
+      for (int tt = G - 1; tt >= 0; --tt) {
+        if (tt < n) {
+#pragma unroll
+          for (int i = 0; i < S; ++i) lam[i] += mine[myC + tt * S + i];
+          float ga, gsv, ua, us;
+          knots(ctl[TCH - G + tt], ua, us);      // still the knots: the sweep has only overwritten the slots behind tt
+          vjp_back_step<MODE>(park[tt], ua, us, lam, cur, a.tie, a.dp, ga, gsv, trig);
+          ctl[TCH - G + tt] = odd ? gsv : ga;    // the knot is dead from here on: its slot takes this lane's gradient
+        }
+      }
+      lds_drain();
+    }
+    if constexpr (NG > 1) {                      // rotate UP circularly: the next (earlier) group moves to [TCH - G, TCH)
+#pragma unroll
+      for (int g = NG - 1; g > 0; --g)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) ck[g][i] = ck[g - 1][i];
+      float tc[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) tc[i] = ctl[TCH - G + i];
+#pragma unroll
+      for (int i = TCH - 1; i >= G; --i) ctl[i] = ctl[i - G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) ctl[i] = tc[i];
+    }
+  }
+  float g0[S0];
+  if constexpr (MODE == IRBFN_ROLLOUT_FULLINT) g0[0] = clipgrad(q0[0], 0.0f, 7.0f, a.tie) * lam[3];
+  else {
+#pragma unroll
+    for (int i = 0; i < S0; ++i) g0[i] = lam[i];
+  }
+
+  // ---- epilogue: gradient rows -> HBM, RPP rows per pass as one contiguous block of whole lines -----------------
+  float* gout = a.gx0u + b0 * L;
+  if (dma) {
+#pragma unroll 1
+    for (int p = 0; p < R / RPP; ++p) {
+      if ((prow / RPP) == p) {
+        float* rr = tile + (prow % RPP) * L;
+        if (!odd) {
+#pragma unroll
+          for (int i = 0; i < S0; ++i) rr[i] = g0[i];
+        }
+        float* cr = rr + S0 + (odd ? T : 0);
+#pragma unroll
+        for (int t = 0; t < TCH; ++t)
+          if (t < T) cr[t] = ctl[t];
+      }
+      lds_drain();
+      float* dst = gout + (long)p * RPP * L;
+      const int nf = RPP * L;                    // multiple of 4 floats; dst is 16-byte aligned
+      for (int v = lane * 4; v < nf; v += 256) {
+        const vf4 val = *reinterpret_cast<const vf4*>(tile + v);
+        __builtin_nontemporal_store(val, reinterpret_cast<vf4*>(dst + v));
+      }
+      lds_drain();
+    }
+  } else if (prow < nvalid) {
+    float* grow = gout + (long)prow * L;
+    if (!odd) {
+#pragma unroll
+      for (int i = 0; i < S0; ++i) grow[i] = g0[i];
+    }
+#pragma unroll
+    for (int t = 0; t < TCH; ++t)
+      if (t < T) grow[S0 + (odd ? T : 0) + t] = ctl[t];
+  }
+}
+
+template <int MODE>
+static int launch_vjp_pair(const float* x0u, const DynParams& dp, const float* gstates, float* g_x0u, int64_t B, int T,
+                           float tie, hipStream_t s) {
+  constexpr int S = VjpTraits<MODE>::S;
+  constexpr int TCH = 50;
+  RollVjp2Args a;
+  a.x0u = x0u; a.gstates = gstates; a.gx0u = g_x0u; a.B = (long)B; a.T = T; a.L = rollout_input_dim(MODE, T);
+  a.tie = tie; a.dp = dp;
+  const int G = vjp_group(TCH);
+  long w = 2L * kVjpPairRows * vjp_pitch(S, G);
+  // the prologue reads TCH knots per lane from a staged row whatever T is: keep those reads inside the wave's tile
+  const long stage = (long)kVjpRPP * a.L + TCH;
+  if (stage > w) w = stage;
+  a.wlds = (int)((w + 3) & ~3L);
+  a.dma_ok = ((reinterpret_cast<uintptr_t>(x0u) | reinterpret_cast<uintptr_t>(gstates) | reinterpret_cast<uintptr_t>(g_x0u)) & 15) == 0 &&
+             ((kVjpRPP * a.L) % 4) == 0;
+  const size_t lds = (size_t)kVjpWaves * a.wlds * sizeof(float);
+  if (lds > 64 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  const long waves = (B + kVjpPairRows - 1) / kVjpPairRows;
+  const dim3 grid((unsigned)((waves + kVjpWaves - 1) / kVjpWaves)), block(kWave * kVjpWaves);
+  hipLaunchKernelGGL((rollout_vjp_pair_kernel<MODE, TCH>), grid, block, lds, s, a);
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
 template <int MODE>
 static int launch_vjp_regs(const float* x0u, const DynParams& dp, const float* gstates, float* g_x0u, int64_t B, int T,
                            float tie, hipStream_t s) {
@@ -659,6 +945,16 @@ int launch_rollout_vjp(int mode, const float* x0u, const DynParams& dp, const fl
   RollVjpArgs a;
   a.x0u = x0u; a.gstates = gstates; a.gx0u = g_x0u; a.B = (long)B; a.T = T;
   a.L = rollout_input_dim(mode, T); a.tie = clip_tie; a.dp = dp;
+#ifndef IRBFN_VJP_PAIR
+#define IRBFN_VJP_PAIR 0
+#endif
+  if (IRBFN_VJP_PAIR && T > 8 && T <= 50) {      // K4p: two lanes per trajectory (A/B builds only, see the note at the kernel)
+    int rc = IRBFN_ERR_UNSUPPORTED;
+    if (mode == IRBFN_ROLLOUT_ST_KS) rc = launch_vjp_pair<IRBFN_ROLLOUT_ST_KS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    else if (mode == IRBFN_ROLLOUT_FULLINT) rc = launch_vjp_pair<IRBFN_ROLLOUT_FULLINT>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    else if (mode == IRBFN_ROLLOUT_FRENET_LS) rc = launch_vjp_pair<IRBFN_ROLLOUT_FRENET_LS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
   if (T >= 1 && T <= 50) {                       // K4 with staged memory traffic (the kernels below: longer horizons)
     int rc = IRBFN_ERR_UNSUPPORTED;
     if (mode == IRBFN_ROLLOUT_ST_KS) rc = launch_vjp_regs<IRBFN_ROLLOUT_ST_KS>(x0u, dp, gstates, g_x0u, B, T, clip_tie, s);
