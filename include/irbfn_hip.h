@@ -316,6 +316,31 @@ int irbfn_mlp_head_vjp(const float* h1_dev, const float* w2_dev, const float* b2
                        const float* gout_dev, float* gh1_dev, float* gw2_dev, float* gb2_dev, float* gw3_dev,
                        float* gb3_dev, int64_t B, int H1, int H2, int O, void* ws_dev, int64_t ws_bytes, void* stream);
 
+/* float64 mode.  The reference trains and evaluates in float64 under --use_float64 (scripts/train_nmpc.py:41-42:
+ * jax.config.update("jax_enable_x64", True); some of its checkpoints hold float64 centers / log_sigs).  These entry points
+ * evaluate WCRBFNet.apply (model.py:169-198) and its parameter VJP (scripts/train_nmpc.py:297-298) in float64 on the f64
+ * vector pipe, straight from the checkpoint-layout arrays: no descriptor, no packed records; the gate bounds are float64 too
+ * (a float32 card would move gamma by delta * 4e-8).  All 13 bases.  The card is a host struct of sizes and DEVICE pointers:
+ * lo / hi [nsplit][max_ranges], delta [nsplit], dim_ranges [n_ranges][nsplit] as for irbfn_net_create.
+ * workspace: irbfn_f64_workspace_bytes(card, B, with_vjp) bytes (gamma [B][R], + the gradient slabs for the VJP).
+ * irbfn_f64_vjp: cotangent gout [B,O] -> g_centers [R,K,D], g_log_sigs [R,K], g_kernel [K,O], g_bias [O]; O <= 16
+ * (IRBFN_ERR_UNSUPPORTED above); deterministic.  Not a throughput path: plain lane-per-query / lane-per-centre kernels. */
+typedef struct irbfn_f64_card {
+  int D, R, K, O, basis, nsplit, max_ranges, n_ranges;
+  const double* lo_dev;
+  const double* hi_dev;
+  const double* delta_dev;
+  const int* dim_ranges_dev;
+} irbfn_f64_card;
+int64_t irbfn_f64_workspace_bytes(const irbfn_f64_card* card, int64_t B, int with_vjp);
+int irbfn_f64_forward(const irbfn_f64_card* card, const double* centers_dev, const double* log_sigs_dev,
+                      const double* kernel_dev, const double* bias_dev, const double* x_dev, double* out_dev, int64_t B,
+                      void* workspace_dev, int64_t workspace_bytes, void* stream);
+int irbfn_f64_vjp(const irbfn_f64_card* card, const double* centers_dev, const double* log_sigs_dev, const double* kernel_dev,
+                  const double* x_dev, const double* gout_dev, double* g_centers_dev, double* g_log_sigs_dev,
+                  double* g_kernel_dev, double* g_bias_dev, int64_t B, void* workspace_dev, int64_t workspace_bytes,
+                  void* stream);
+
 /* Diagnostics */
 int irbfn_abi_version(void);
 int irbfn_device_count(void);

@@ -64,12 +64,22 @@ SIGNATURES = {
     "irbfn_mlp_head_forward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp]),
     "irbfn_mlp_head_vjp_workspace_bytes": (_i64, [_i, _i, _i]),
     "irbfn_mlp_head_vjp": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "irbfn_f64_workspace_bytes": (_i64, [_vp, _i64, _i]),
+    "irbfn_f64_forward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _vp, _i64, _vp]),
+    "irbfn_f64_vjp": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _vp, _i64, _vp]),
     "irbfn_abi_version": (_i, []),
     "irbfn_device_count": (_i, []),
     "irbfn_last_hip_error": (_i, []),
     "irbfn_strerror": (C.c_char_p, [_i]),
     "irbfn_net_last_launch": (_i, [_vp, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
 }
+
+class F64Card(C.Structure):
+    """irbfn_f64_card (include/irbfn_hip.h): sizes + device pointers of the float64 gate tables."""
+    _fields_ = [("D", C.c_int), ("R", C.c_int), ("K", C.c_int), ("O", C.c_int), ("basis", C.c_int), ("nsplit", C.c_int),
+                ("max_ranges", C.c_int), ("n_ranges", C.c_int), ("lo_dev", C.c_void_p), ("hi_dev", C.c_void_p),
+                ("delta_dev", C.c_void_p), ("dim_ranges_dev", C.c_void_p)]
+
 
 _lock = threading.Lock()
 _lib = None

@@ -78,7 +78,7 @@ class WCRBFNet:
                  num_regions: int, lower_bounds: Sequence[Sequence[float]],
                  upper_bounds: Sequence[Sequence[float]], dimension_ranges: Sequence[Sequence[int]],
                  activation_idx: Sequence[int], delta: Sequence[float], centers=None,
-                 fixed_centers: bool = False, fixed_width: bool = False, **_unused):
+                 fixed_centers: bool = False, fixed_width: bool = False, use_float64: bool = False, **_unused):
         self.in_features = int(in_features)
         self.out_features = int(out_features)
         self.num_kernels = int(num_kernels)
@@ -90,6 +90,11 @@ class WCRBFNet:
         self.activation_idx = list(activation_idx)
         self.delta = list(map(float, delta))
         self.fixed_centers, self.fixed_width = bool(fixed_centers), bool(fixed_width)
+        # float64 mode = the reference's --use_float64 (scripts/train_nmpc.py:41-42): apply / vjp evaluate in float64 on the
+        # GPU (irbfn_f64_*: plain f64 kernels, not the tuned float32 path) and return float64
+        self.use_float64 = bool(use_float64)
+        self._f64 = {}
+        self._warned_f64 = False
         self.num_split_dimensions = len(self.activation_idx)          # model.py:128
         ns = self.num_split_dimensions
         if ns > self.in_features:
@@ -109,16 +114,17 @@ class WCRBFNet:
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
-    def from_config(cls, cfg) -> "WCRBFNet":
+    def from_config(cls, cfg, use_float64: bool = False) -> "WCRBFNet":
         """cfg: dict, argparse.Namespace or path of a YAML model card (the file the reference writes at
-        scripts/train_nmpc.py:431-450 and reloads at src/irbfn_mpc/irbfn_planner.py:46-79)."""
+        scripts/train_nmpc.py:431-450 and reloads at src/irbfn_mpc/irbfn_planner.py:46-79).  The card does not record
+        --use_float64 (a process-wide jax flag in the reference): pass ``use_float64=True`` for that mode."""
         if isinstance(cfg, str):
             import yaml
             with open(cfg, "r") as f:
                 cfg = yaml.safe_load(f)
         elif not isinstance(cfg, dict):
             cfg = vars(cfg)
-        return cls(**{k: cfg[k] for k in _CFG_FIELDS})
+        return cls(**{k: cfg[k] for k in _CFG_FIELDS}, use_float64=use_float64 or bool(cfg.get("use_float64", False)))
 
     def config(self) -> dict:
         return {k: getattr(self, k) for k in _CFG_FIELDS}
@@ -266,9 +272,108 @@ class WCRBFNet:
 
     def apply(self, params: dict, x):
         """Drop-in for ``WCRBFNet.apply(params, x)`` / ``state.apply_fn(state.params, x)``
-        (src/irbfn_mpc/irbfn_planner.py:31)."""
+        (src/irbfn_mpc/irbfn_planner.py:31).  ``use_float64=True``: evaluated in float64 (``apply64``)."""
+        if self.use_float64:
+            return self.apply64(params, x)
+        self._warn_if_float64(params)
         self.bind(params)
         return self(x)
+
+    # ------------------------------------------------------------------ float64 mode
+    def _warn_if_float64(self, params: dict):
+        """A --use_float64 checkpoint (float64 centers / log_sigs) handed to the float32 path: say so once."""
+        if self._warned_f64:
+            return
+        p = _inner(params)
+        dts = {str(getattr(p[g][n], "dtype", "")) for g, n in (("rbf_list", "centers"), ("rbf_list", "log_sigs"),
+                                                                 ("linear", "kernel"), ("linear", "bias"))}
+        if any("float64" in d for d in dts):
+            import warnings
+            warnings.warn("WCRBFNet: float64 parameter leaves are evaluated in float32 (within 1e-5 of a float64 run); construct "
+                          "the net with use_float64=True for the float64 mode of the reference (--use_float64)", stacklevel=3)
+            self._warned_f64 = True
+
+    def _f64_card(self, torch):
+        dev = torch.cuda.current_device()
+        ent = self._f64.get(dev)
+        if ent is None:
+            ns = self.num_split_dimensions
+            mr = max([1] + [max(len(self.lower_bounds[d]), len(self.upper_bounds[d])) for d in range(ns)])
+            lo = np.zeros((max(ns, 1), mr), np.float64)
+            hi = np.zeros((max(ns, 1), mr), np.float64)
+            for d in range(ns):
+                lo[d, :len(self.lower_bounds[d])] = self.lower_bounds[d]
+                hi[d, :len(self.upper_bounds[d])] = self.upper_bounds[d]
+            nr = min(len(self.dimension_ranges), self.num_regions)
+            dr = np.asarray([r[:ns] for r in self.dimension_ranges[:nr]], np.int32).reshape(nr, max(ns, 0))
+            tens = [torch.from_numpy(a).cuda() for a in (lo, hi, np.asarray(self.delta[:ns] if ns else [0.0], np.float64),
+                                                         np.ascontiguousarray(dr if dr.size else np.zeros((1, 1), np.int32)))]
+            card = _lib.F64Card(self.in_features, self.num_regions, self.num_kernels, self.out_features,
+                                _lib.BASIS_ENUM[self.basis_func], ns, mr, nr, tens[0].data_ptr(), tens[1].data_ptr(),
+                                tens[2].data_ptr(), tens[3].data_ptr())
+            ent = (card, tens, {})
+            self._f64[dev] = ent
+        return ent
+
+    @staticmethod
+    def _dev_f64(a, torch):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+        return t.to(device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float64).contiguous()
+
+    def _f64_ws(self, torch, ent, nbytes):
+        ws = ent[2].get("ws")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty((max(int(nbytes), 8),), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+            ent[2]["ws"] = ws
+        return ws
+
+    def apply64(self, params: dict, x):
+        """``apply`` in float64 (the reference under --use_float64, scripts/train_nmpc.py:41-42) -> float64 [B,O]."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        self._check_shapes(p)
+        ent = self._f64_card(torch)
+        card = ent[0]
+        c, l, k, b = (self._dev_f64(a, torch) for a in (p["rbf_list"]["centers"], p["rbf_list"]["log_sigs"], p["linear"]["kernel"],
+                                                        p["linear"]["bias"]))
+        xd = self._dev_f64(x, torch)
+        if xd.dim() != 2 or xd.shape[1] != self.in_features:
+            raise ValueError(f"x must have shape (B, {self.in_features}), got {tuple(xd.shape)}")
+        B = xd.shape[0]
+        out = torch.empty((B, self.out_features), dtype=torch.float64, device=xd.device)
+        nbytes = int(lib.irbfn_f64_workspace_bytes(C.byref(card), B, 0))
+        ws = self._f64_ws(torch, ent, nbytes)
+        st = lib.irbfn_f64_forward(C.byref(card), _ptr(c), _ptr(l), _ptr(k), _ptr(b), _ptr(xd), _ptr(out), B, _ptr(ws), nbytes,
+                                   _stream_ptr(torch))
+        _lib.check(st, "irbfn_f64_forward")
+        return like_input(out, x, torch)
+
+    def vjp64(self, params: dict, x, gout) -> dict:
+        """Parameter VJP in float64 (``jax.value_and_grad`` of the reference under --use_float64) -> float64 gradient pytree."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        p = _inner(params)
+        self._check_shapes(p)
+        ent = self._f64_card(torch)
+        card = ent[0]
+        c, l, k = (self._dev_f64(a, torch) for a in (p["rbf_list"]["centers"], p["rbf_list"]["log_sigs"], p["linear"]["kernel"]))
+        xd, gd = self._dev_f64(x, torch), self._dev_f64(gout, torch)
+        B = xd.shape[0]
+        if tuple(gd.shape) != (B, self.out_features):
+            raise ValueError(f"gout must have shape ({B}, {self.out_features}), got {tuple(gd.shape)}")
+        R, K, D, O = self.num_regions, self.num_kernels, self.in_features, self.out_features
+        gc = torch.empty((R, K, D), dtype=torch.float64, device=xd.device)
+        gl = torch.empty((R, K), dtype=torch.float64, device=xd.device)
+        gk = torch.empty((K, O), dtype=torch.float64, device=xd.device)
+        gb = torch.empty((O,), dtype=torch.float64, device=xd.device)
+        nbytes = int(lib.irbfn_f64_workspace_bytes(C.byref(card), B, 1))
+        ws = self._f64_ws(torch, ent, nbytes)
+        st = lib.irbfn_f64_vjp(C.byref(card), _ptr(c), _ptr(l), _ptr(k), _ptr(xd), _ptr(gd), _ptr(gc), _ptr(gl), _ptr(gk), _ptr(gb),
+                               B, _ptr(ws), nbytes, _stream_ptr(torch))
+        _lib.check(st, "irbfn_f64_vjp")
+        conv = lambda t: like_input(t, x, torch)
+        return {"params": {"rbf_list": {"centers": conv(gc), "log_sigs": conv(gl)}, "linear": {"kernel": conv(gk), "bias": conv(gb)}}}
 
     def gate(self, x):
         """``_region_activation`` (model.py:42-95): x[B,D] -> gamma[B,R]."""
@@ -287,8 +392,11 @@ class WCRBFNet:
         """Parameter VJP: cotangent gout[B,O] -> gradient pytree (same structure as ``params``).
         Replaces ``jax.value_and_grad(loss_fn)(params)`` restricted to the network
         (scripts/train_nmpc.py:297-298).  Gradients w.r.t. x are never taken by the reference."""
+        if self.use_float64 and out is None:
+            return self.vjp64(params, x, gout)
         torch = _lib.require_gpu()
         lib = _lib.load()
+        self._warn_if_float64(params)
         self.bind(params)
         xd, gd = to_device_f32(x, torch), to_device_f32(gout, torch)
         B = xd.shape[0]
