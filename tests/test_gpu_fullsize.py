@@ -14,8 +14,23 @@ from oracle import c_oracle as co
 from oracle import irbfn_oracle as orc
 from test_gpu_parity import assert_states_close
 
+import os
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5          # north_star tolerance
+_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize.txt")
+
+
+def record(line: str):
+    """The measured error figures of the full-size comparisons, printed AND kept: gpurun_out/parity_fullsize.txt on the GPU box
+    (copied to profiles/r<NN>_parity_fullsize.txt for the round's evidence)."""
+    print(line)
+    try:
+        os.makedirs(os.path.dirname(_LOG), exist_ok=True)
+        with open(_LOG, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
 LEAVES = (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias"))
 
 
@@ -39,7 +54,7 @@ def test_cfg2_forward_full_batch(gpu):
     err = np.abs(got - ref)
     with np.errstate(divide="ignore", invalid="ignore"):
         q999 = np.quantile(err / np.abs(ref), 0.999)
-    print(f"cfg-2 full batch: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, max |err| / sum|terms| = {(err / scale).max():.2e}, "
+    record(f"cfg-2 full batch: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, max |err| / sum|terms| = {(err / scale).max():.2e}, "
           f"plain relative error: 99.9 % of the outputs below {q999:.2e}")
     assert err.max() <= RTOL * np.abs(ref).max()
     assert (err <= RTOL * np.abs(ref) + 3e-6 * scale).all()
@@ -60,7 +75,7 @@ def test_cfg3_vjp_full_batch(gpu):
         ga, gr = a[grp][name].cpu().numpy().astype(np.float64), ref[grp][name]
         scale = np.abs(gr).max()
         e = np.abs(ga - gr).max() / scale
-        print(f"cfg-3 d {name}: max |err| / max |ref| = {e:.2e}")
+        record(f"cfg-3 d {name}: max |err| / max |ref| = {e:.2e}")
         assert e <= 2e-5, (name, e)
     a2 = net.vjp(P, xt, gt)["params"]
     b = net.vjp(P, xt, gt * 4.0)["params"]
@@ -100,7 +115,7 @@ def test_cfg4_share_forward_and_tick(gpu):
     ref = co.wcrbf_forward(cfg, P, x[sub], np.float64)
     scale = _terms_scale(cfg, P, x[sub])
     err = np.abs(u.cpu().numpy()[sub].astype(np.float64) - ref)
-    print(f"cfg-4 forward: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, / sum|terms| = {(err / scale).max():.2e}")
+    record(f"cfg-4 forward: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, / sum|terms| = {(err / scale).max():.2e}")
     assert err.max() <= RTOL * np.abs(ref).max() and (err <= RTOL * np.abs(ref) + 3e-6 * scale).all()
     rows = sub[:1024]
     dp = np.array(configs.DYN_PARAMS)
@@ -151,7 +166,7 @@ def test_cfg5_forward_full_batch(gpu):
     ref = co.wcrbf_forward(cfg, P, x[rows], np.float64)
     scale = _terms_scale(cfg, P, x[rows])
     err = np.abs(out.cpu().numpy()[rows].astype(np.float64) - ref)
-    print(f"cfg-5: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, / sum|terms| = {(err / scale).max():.2e}")
+    record(f"cfg-5: max |err| / max |ref| = {err.max() / np.abs(ref).max():.2e}, / sum|terms| = {(err / scale).max():.2e}")
     assert err.max() <= RTOL * np.abs(ref).max() and (err <= RTOL * np.abs(ref) + 3e-6 * scale).all()
     perm = torch.from_numpy(np.random.default_rng(0).permutation(1 << 20)).cuda()          # same batch size = same launch geometry
     assert torch.equal(net.apply(P, xt[perm].contiguous()), out[perm])
