@@ -7,21 +7,23 @@
 // has gamma != 0 in 4-6 of 128 (or 12) regions.  Skipping gamma == 0 changes no result (0 * phi, phi finite).
 //
 // K1's skip is per WAVE (a region is skipped when all 64 queries of a wave have gamma == 0), which never fires on a
-// batch in arrival order.  Here every LANE walks its own list of active regions:
-//   1. the net's centres {c[D], folded width} sit in LDS (whole net: 43 KB for 128 regions x 10 centres), the Dense
-//      weights are wave-uniform (k is; the region is not) and stream through the scalar cache;
-//   2. a lane evaluates the per-(dimension, range) factors of its query once (E <= 32 of them, LDS column), keeps
-//      "factor != 0" as a bit mask M, and a wave-uniform scan over the regions appends r to the lane's list when
-//      (M & req[r]) == req[r]  (req[r] = the factor bits region r multiplies);
-//   3. the (query, active region) pairs of a workgroup are numbered query-major (prefix sum of the list lengths) and
-//      dealt to the lanes round by round, one pair per lane and round: the list lengths are very uneven (mean 3.6,
-//      max 32 on the 128-region planner -- a corner of the gate grid) and a lane that walked its own list would hold
-//      its whole wave for the longest one (measured: 62 us at any batch size, the time of ONE 32-region query);
-//   4. a lane finds its pair's query by binary search in the prefix sums, reads the region, forms gamma (product of
-//      the region's factors in the order of the reference's loop, model.py:88-93 -- bit-identical to the dense
-//      kernels' gamma) and runs the K centres of that region: per-lane LDS reads of the centre, wave-uniform weight
-//      rows; the pair's partial output goes to an LDS tile and the query's own lane adds its pairs in region order.
-// Result per query = sum over its active regions in ascending region order of the per-region sums: deterministic,
+// batch in arrival order.  Here a query's live regions are found per LANE and the (query, region) pairs are the unit of work:
+//   1. the net sits in LDS as ONE image (sp_img_layout: region masks and index words, factor entries, Dense weight rows,
+//      centre table {c[D], folded width} -- 43 KB for 128 regions x 10 centres), copied by LDS-DMA; everything a lane later
+//      reads by a wave-uniform address is a broadcast LDS read, never a scalar load the wave would stall on;
+//   2. a lane evaluates the per-(dimension, range) factors of its query once (E <= 32 of them, LDS column) and keeps
+//      "factor != 0" as a bit mask M; region r is live iff (M & req[r]) == req[r] (req[r] = the factor bits region r
+//      multiplies): 32 regions at a time become one bit word without a branch;
+//   3. the (query, live region) pairs of a workgroup are numbered query-major (prefix sum of the popcounts), written out
+//      as flat arrays (region, owner) and dealt to the lanes round by round, one pair per lane and round: the list lengths
+//      are very uneven (mean 3.6, max 32 on the 128-region planner -- a corner of the gate grid) and a lane that walked its
+//      own list would hold its whole wave for the longest one (measured: 62 us at any batch size, the time of ONE
+//      32-region query);
+//   4. a lane forms gamma of its pair (product of the region's factors in the order of the reference's loop,
+//      model.py:88-93 -- bit-identical to the dense kernels' gamma) and runs the K centres of that region: per-lane LDS
+//      reads of the centre, broadcast reads of the weight rows; the pair's partial output goes to an LDS tile and the
+//      query's own lane adds its pairs in region order.
+// Result per query = sum over its live regions in ascending region order of the per-region sums: deterministic,
 // independent of the batch it is part of and of which lane served which pair, and equal to the dense kernels up to
 // the order of the float32 sum (K1 splits the centres over waves).
 //
