@@ -249,3 +249,55 @@ def test_sparse_forward_large_batch_gathers_the_centre_table_from_global_memory(
     assert "GC=1" in net.last_launch()["kernel"] and "ROLL=1" in net.last_launch()["kernel"]
     c2, s2 = planner.plan_tick(net, P, x[:3000].contiguous(), None, s0[:3000].contiguous(), configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
     assert torch.equal(ctrl[:3000], c2) and torch.equal(states[:3000], s2) and torch.equal(ctrl, big)
+
+
+@pytest.mark.parametrize("basis", ["gaussian", "inverse_multiquadric"])
+def test_sparse_kernels_on_a_synthetic_grid_of_300_regions(gpu, basis):
+    """Shapes the reference's fixtures do not reach: 300 regions (more than 256: 16-bit region lists; not a multiple of 32 or
+    64), d = 3, O = 5, an odd number of centres per region (tail of the two-centre step), three split dimensions,
+    dimension_ranges shorter than R (App. B-2: the last 12 regions stay 0).  Forward, tick-free VJP against the dense
+    kernels and the float64 oracle; ragged batches."""
+    import torch
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(11)
+    nx, ny, nz = 12, 12, 2                                    # 288 ranges for 300 regions, 26 gate factors (<= 32)
+    ex, ey, ez = np.linspace(0.0, 9.0, nx + 1), np.linspace(-4.0, 4.0, ny + 1), np.linspace(-1.3, 1.3, nz + 1)
+    cfg = {"in_features": 3, "out_features": 5, "num_kernels": 7, "basis_func": basis, "num_regions": 300,
+           "activation_idx": [0, 1, 2], "delta": [40.0, 40.0, 15.0],
+           "lower_bounds": [list(ex[:-1]), list(ey[:-1]), list(ez[:-1])], "upper_bounds": [list(ex[1:]), list(ey[1:]), list(ez[1:])],
+           "dimension_ranges": [[i, j, k] for i in range(nx) for j in range(ny) for k in range(nz)]}
+    R, K, D, O = 300, 7, 3, 5
+    ctr = np.zeros((R, K, D))
+    for r, (i, j, k) in enumerate(cfg["dimension_ranges"]):
+        ctr[r] = np.stack([rng.uniform(ex[i], ex[i + 1], K), rng.uniform(ey[j], ey[j + 1], K), rng.uniform(ez[k], ez[k + 1], K)], axis=1)
+    ctr[288:] = rng.normal(size=(12, K, D))
+    P = {"params": {"rbf_list": {"centers": ctr.astype(np.float32), "log_sigs": rng.uniform(-1.0, 0.5, size=(R, K)).astype(np.float32)},
+                    "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    for B in (70, 1000, 4097):
+        x = np.stack([rng.uniform(0, 9, B), rng.uniform(-4, 4, B), rng.uniform(-1.3, 1.3, B)], axis=1)
+        x[::7, 0] = ex[rng.integers(1, nx, len(x[::7]))] + rng.choice([0.0, 0.01, -0.01], len(x[::7]))      # on / next to borders
+        x = x.astype(np.float32)
+        ref = orc.wcrbfnet_apply(cfg, orc.cast_params(P, np.float64), x.astype(np.float64))
+        _, h, gamma = orc.wcrbfnet_apply(cfg, orc.cast_params(P, np.float64), x.astype(np.float64), return_aux=True)
+        cancel = np.abs(h) @ np.abs(P["params"]["linear"]["kernel"].astype(np.float64)) + 1e-30
+        net = WCRBFNet.from_config(cfg)
+        net.set_options(fwd_kernel=_lib.FWD_K1R)
+        sp = net.apply(P, x)
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_sparse<D=3,OP=5")
+        net.set_options(fwd_kernel=_lib.FWD_K1)
+        dn = net.apply(P, x)
+        assert (np.abs(sp - dn) <= 2e-6 * cancel + 1e-6 * np.abs(ref)).all(), (basis, B, np.abs(sp - dn).max())
+        assert (np.abs(sp - ref) <= 1e-5 * np.abs(ref) + 3e-6 * cancel + 1e-6).all(), (basis, B)
+        g = rng.normal(size=(B, O)).astype(np.float32)
+        refg = co.wcrbf_vjp(cfg, P, x, g, np.float64)["params"]
+        net.set_options(vjp_kernel=_lib.VJP_K2R)
+        a = net.vjp(P, x, g)["params"]
+        b = net.vjp(P, x, g)["params"]
+        net.set_options(vjp_kernel=_lib.VJP_K2)
+        d = net.vjp(P, x, g)["params"]
+        for grp, name in LEAVES:
+            assert np.array_equal(a[grp][name], b[grp][name])
+            scale = np.abs(refg[grp][name]).max() + 1e-30
+            assert np.abs(a[grp][name] - refg[grp][name]).max() <= 5e-5 * scale, (basis, B, name)
+            assert np.abs(a[grp][name] - d[grp][name]).max() <= 2e-5 * scale, (basis, B, name)
+        assert not a["rbf_list"]["centers"][288:].any() and not a["rbf_list"]["log_sigs"][288:].any()      # regions without a range
