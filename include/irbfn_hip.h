@@ -127,7 +127,8 @@ typedef enum irbfn_fwd_kernel {
   IRBFN_FWD_K1 = 1,   /* rbf_fwd_qlane: all-float32 VALU kernel (any net) */
   IRBFN_FWD_K1M = 2,  /* rbf_fwd_mfma: Phi x W on the f32-input matrix cores */
   IRBFN_FWD_K1H = 3,  /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
-  IRBFN_FWD_K1R = 4   /* rbf_fwd_sparse: several regions, every query visits only the regions whose gamma != 0 */
+  IRBFN_FWD_K1R = 4,  /* rbf_fwd_sparse: several regions, every query visits only the regions whose gamma != 0 */
+  IRBFN_FWD_K1G = 5   /* rbf_fwd_f16gram: one region, O <= 16: distances as a Gram expansion on the f16 matrix cores as well */
 } irbfn_fwd_kernel;
 typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3 } irbfn_vjp_kernel;
 /* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */

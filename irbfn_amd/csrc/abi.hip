@@ -87,6 +87,10 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
     alloc((void**)&net->f16_img, f16_image_bytes(net));
     alloc((void**)&net->f16_oscale, 128 * sizeof(float));
   }
+  if (gram_eligible(net)) {
+    alloc((void**)&net->gram_img, gram_image_bytes(net));
+    alloc((void**)&net->gram_hdr, gram_header_bytes());
+  }
   alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
   alloc((void**)&net->small_ticket, small_ticket_count() * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMemset(net->small_ticket, 0, small_ticket_count() * sizeof(unsigned int));
@@ -121,7 +125,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
 
 int irbfn_net_destroy(irbfn_net* net) {
   if (!net) return IRBFN_OK;
-  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->gram_img, net->gram_hdr, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   sparse_free(net);
@@ -135,6 +139,7 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
   int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->recm) rc = launch_pack_mfma(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->f16_img) rc = launch_pack_f16(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
+  if (rc == IRBFN_OK && net->gram_img) rc = launch_pack_gram(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->sp_ok) rc = launch_pack_sparse(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
@@ -143,7 +148,7 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
 int irbfn_net_set_option(irbfn_net* net, int option, int value) {
   if (!net || option < 0 || option >= IRBFN_OPT_COUNT || value < 0) return IRBFN_ERR_BAD_ARG;
   switch (option) {
-    case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1R) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1G) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2R) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_SMALL: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 2 && value != 3) return IRBFN_ERR_BAD_ARG; break;
@@ -151,7 +156,7 @@ int irbfn_net_set_option(irbfn_net* net, int option, int value) {
     case IRBFN_OPT_FWD_NW: if (value > 16) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_QJ: if (value != 0 && value != 1 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_F16_S:
-    case IRBFN_OPT_FWD_F16_QG: if (value > 8) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_FWD_F16_QG: if (value > 16) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_VJP_F16_CT: if (value != 0 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_LDS_PAD: if (value > 128 * 1024) return IRBFN_ERR_BAD_ARG; break;
     default: break;

@@ -76,6 +76,10 @@ struct irbfn_net {
   int Npad;     // N rounded up to a multiple of 16 (MFMA chunk)
   unsigned char* f16_img;   // chunk images of the f16-split matrix-core forward (K1h); NULL if not eligible
   float* f16_oscale;        // [128] per-output power-of-two scale of the K1h weight split
+  unsigned char* gram_img;  // chunk images of K1g (distances as a Gram expansion on the matrix cores); NULL if not eligible
+  void* gram_hdr;           // K1g: origin and exponents of the expansion (device, written by the pack)
+  int gram_ok;              // K1g: the parameters fit the expansion's exactness budget (read back by set_params)
+  int gram_exp[5];          // K1g: exponents ex, ec, eq, ea, e2 (diagnostics)
   float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
   unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs
@@ -116,6 +120,15 @@ bool f16_eligible(const irbfn_net* net);
 size_t f16_image_bytes(const irbfn_net* net);
 int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s);
+bool gram_eligible(const irbfn_net* net);
+bool gram_preferred(const irbfn_net* net, int64_t B);
+void gram_geometry(const irbfn_net* net, int64_t B, int* S, int* QG);
+size_t gram_image_bytes(const irbfn_net* net);
+size_t gram_header_bytes();
+int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
+int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, hipStream_t s);
+int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0, const DynParams& dp,
+                            float* controls, float* states, int64_t B, int T, hipStream_t s);
 bool tick_through_controls(const irbfn_net* net, int64_t B);
 bool f16_narrow_geometry(const irbfn_net* net, int64_t B, int* S, int* QG);
 bool tick_f16_narrow_available(const irbfn_net* net, int mode, int64_t B, int T);

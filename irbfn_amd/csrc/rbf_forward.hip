@@ -320,6 +320,28 @@ bool f16_narrow_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_ou
   return true;
 }
 
+// K1g (rbf_forward_gram.hip): where K1h's narrow kernel would run with its default operand pairs and the parameters fit the
+// expansion (gram_ok, set by the pack)
+bool gram_preferred(const irbfn_net* net, int64_t B) {
+  const int ot = net->opt[IRBFN_OPT_FWD_F16_TERMS];
+  return net->gram_img && net->gram_ok && net->O <= 16 && (ot == 3 || ot == 0) && B >= opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65);
+}
+
+// S centre slices x QG query groups: the QG waves of a slice share one stream of chunk images, so QG is as large as the
+// batch allows while the launch still has ~4 waves per SIMD
+void gram_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_out) {
+  const long groups = (B + 31) / 32;
+  const int nchunks = (net->N + 31) / 32;
+  // measured at config 2 (B = 65536, N = 4096): S = 2, QG = 4 85 us; S = 1, QG = 4 88; S = 1, QG = 8 96; S = 2, QG = 8 93
+  int S = 1;
+  while (S < 4 && groups * S < 4096 && nchunks / (2 * S) >= 4) S *= 2;     // a slice's ring is 21 KiB of LDS
+  S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
+  if (S > 7 || S > nchunks) S = 1;
+  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
+  if (S * QG > 16) QG = 1;
+  *S_out = S; *QG_out = QG;
+}
+
 static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s) {
   const int e = net->opt[IRBFN_OPT_FWD_KERNEL];
   if (e != IRBFN_FWD_AUTO && e != IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
@@ -333,6 +355,12 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   }
   int S, QG;
   if (!f16_narrow_geometry(net, B, &S, &QG)) return IRBFN_ERR_UNSUPPORTED;
+  if (e == IRBFN_FWD_AUTO && gram_preferred(net, B)) {         // K1g: the distances on the matrix cores as well
+    int Sg, QGg;
+    gram_geometry(net, B, &Sg, &QGg);
+    const int rc = launch_forward_gram(net, x, out, B, Sg, QGg, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+  }
   const int ot = net->opt[IRBFN_OPT_FWD_F16_TERMS];
   const int terms = (ot == 1 || ot == 2) ? ot : 3;           // 1: plain f16, 2: plain bf16 (both reporting only), 3: pairs
   return launch_forward_f16(net, x, out, B, S, QG, terms, s);
@@ -353,6 +381,12 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
   }
   // a kernel that is "not eligible" answers IRBFN_ERR_UNSUPPORTED; every other status (a HIP launch failure
   // of the preferred kernel in particular) is returned, never papered over by the next kernel in line
+  if (forced == IRBFN_FWD_K1G) {
+    if (!net->gram_img || !net->gram_ok || net->O > 16) return IRBFN_ERR_UNSUPPORTED;
+    int Sg, QGg;
+    gram_geometry(net, B, &Sg, &QGg);
+    return launch_forward_gram(net, x, out, B, Sg, QGg, s);
+  }
   int rc = try_forward_f16(net, x, out, B, s);
   if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
   if (forced == IRBFN_FWD_K1H) return IRBFN_ERR_UNSUPPORTED;
@@ -387,6 +421,8 @@ int launch_forward_rollout(irbfn_net* net, int mode, const float* x, const int* 
   {
     // K1h nets: the whole tick in one launch where the instance exists (wide: plan_tick_wide.hip; narrow: rbf_tick_f16mfma)
     int rc = launch_tick_f16_wide(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
+    if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+    rc = launch_tick_gram_narrow(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
     rc = launch_tick_f16_narrow(net, mode, x, mirror, state0, dp, controls, states, B, T, s);
     if (rc != IRBFN_ERR_UNSUPPORTED) return rc;

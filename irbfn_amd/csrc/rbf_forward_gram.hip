@@ -1,0 +1,740 @@
+// K1g: the narrow forward (one region, O <= 16, fast bases) with BOTH of its GEMM-shaped pieces on the f16 matrix cores:
+// the squared distances as a Gram expansion and Phi x W (the hi/lo pairs of K1h).  Same mathematics as K1 / K1h
+// (src/irbfn_mpc/model.py:169-198; RBF stage flax_rbf.py:258-285).
+//
+// Why: K1h is VALU-issue bound, and 14 of its ~21.5 VALU instructions per (query, centre) pair are the distance
+// (x_i - c_i, fma) x 7.  With u = alpha_k |x - c_k|^2 + beta (the argument of the transcendental) written as
+//     u = alpha_k Q  +  sum_i (-2 alpha_k c'_ki) x'_i  +  (alpha_k |c'_k|^2 + beta),      x' = x - r, c' = c - r, Q = |x'|^2
+// it is a [centres x slots] x [slots x queries] product whose D layout (v_mfma: lane = query column, registers = 4 centre
+// rows) is already the A layout of the Phi x W product: no shuffle between the two.  What is left on the VALU per pair is the
+// transcendental and the hi/lo split of its result.
+//
+// Accuracy -- the expansion cancels (terms of size M = alpha (|x'|^2 + |c'|^2) sum to u <~ 30), and the matrix core adds its
+// products in a tree of truncating ~24-bit adders (tools/probe_mfma_accum.hip, profiles/r03_mfma_accumulation_probe.txt), so a
+// naive expansion carries an error of 2^-24 M.  Here the cancellation is EXACT:
+//  * every factor v in {x'_i, Q, C_ki = -2 alpha_k c'_ki, alpha_k, c2_k} with |v| < 2^E is cut into a FIXED-POINT head
+//    n0 = rint(v 2^(10-E)) 2^-10 (11 bits: exact in f16) and two float tails n1, n2 (f16 roundings of the scaled residuals:
+//    v = 2^E (n0 + 2^-11 n1 + 2^-22 n2) to 2^(E-34)); c2 has two fixed-point heads;
+//  * the head x head products of one (query, centre) element are integer multiples of one grid 2^(EX+EC-20) and their partial
+//    sums stay below 2^24 grid units (checked at pack time): whatever the order of the adder tree, nothing is truncated --
+//    the first MFMA (16x16x16, 10 of its 16 k-slots) returns the cancelled head sum S1 exactly;
+//  * the 42 tail products (each < 2^-10 of a head product) are added to S1 by two 16x16x32 MFMAs: truncation there is
+//    2^-24 of max(|u|, 2^-10 M).
+// So u carries the error of a float32 evaluation of the direct form (a few 2^-24 |u|), not 2^-24 M.  Exponents EX .. E2 are
+// chosen per net from the centres (gram_stats_kernel); a query outside the representable box (|x'_i| >= 2^EX, non-finite)
+// makes its WAVE take the VALU distances of K1h for its 32 queries (same records, same f16_arg): results there are K1h's.
+// A net whose exponents do not fit (ok = 0 in the header, read back once by irbfn_net_set_params) is not dispatched here.
+//
+// Layout: v_mfma_f32_16x16x16_f16 / 16x16x32_f16 with rows = 16 centres, k = slots, columns = 16 queries.  A lane owns
+// query (l & 15) of its wave's two query tiles; the D registers of centre tile ct hold centres 16 ct + 4 g + r (g = l >> 4),
+// which become k-slots 8 g + 4 ct + r of the Phi x W product (the W rows of the image are permuted to match).
+// Chunk image (32 centres, 7 KiB): head operands [ct][lane] 8 B, tail operands [ct][half][lane] 16 B, W hi, W lo (1 KiB each);
+// the QG waves of a centre slice share an LDS ring of three images filled by LDS-DMA, one barrier per chunk.
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "rbf_forward_f16_narrow.h"
+
+namespace irbfn {
+
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kGramHeadBytes = 2 * 64 * 8;                       // [ct][lane] 4 halfs
+constexpr int kGramTailBytes = 2 * 2 * 64 * 16;                  // [ct][half][lane] 8 halfs
+constexpr int kGramChunkBytes = kGramHeadBytes + kGramTailBytes + 2 * kF16WBytes;   // 7 KiB
+constexpr int kGramDims = 7;
+#ifndef IRBFN_GRAM_WAVES
+#define IRBFN_GRAM_WAVES 4     // waves per SIMD the register allocation must allow
+#endif
+
+struct GramHdr {
+  float r[8];                 // origin (midpoint of the centres' box)
+  int ex, ec, eq, ea, e2;     // |x'_i| < 2^ex, |C| < 2^ec, Q < 2^eq, |alpha| < 2^ea, |c2| < 2^e2
+  int ok;
+  float cabs, amax, cmax, c2max;
+};
+
+// ---- the slot tables: which product sits in which k-slot ---------------------------------------------------------
+struct GramSlot { int kind, dim, p, q; };        // kind: 0 empty, 1 x'_dim part p x C part q, 2 Q part p x alpha part q, 3 1 x c2 part p
+__host__ __device__ constexpr GramSlot gram_head_slot(int s) {
+  return s < kGramDims ? GramSlot{1, s, 0, 0}
+                       : (s == 7 ? GramSlot{2, 0, 0, 0} : (s == 8 ? GramSlot{3, 0, 0, 0} : (s == 9 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})));
+}
+__host__ __device__ constexpr int gram_comb_p(int m) { return m == 0 ? 0 : (m == 1 ? 1 : (m == 2 ? 0 : (m == 3 ? 2 : 1))); }
+__host__ __device__ constexpr int gram_comb_q(int m) { return m == 0 ? 1 : (m == 1 ? 0 : (m == 2 ? 2 : (m == 3 ? 0 : 1))); }
+__host__ __device__ constexpr GramSlot gram_tail_slot(int s) {
+  return s < 5 * kGramDims ? GramSlot{1, s / 5, gram_comb_p(s % 5), gram_comb_q(s % 5)}
+                           : (s < 5 * kGramDims + 5 ? GramSlot{2, 0, gram_comb_p(s - 5 * kGramDims), gram_comb_q(s - 5 * kGramDims)}
+                                                    : (s < 5 * kGramDims + 7 ? GramSlot{3, 0, s - 5 * kGramDims - 5 + 2, 0} : GramSlot{0, 0, 0, 0}));
+}
+// power-of-two weight of a slot's product and its split between the two operands (both kept near 2^(T/2))
+__host__ __device__ inline int gram_T(const GramHdr& h, const GramSlot sl) {
+  return sl.kind == 1 ? h.ex + h.ec - 11 * (sl.p + sl.q) : (sl.kind == 2 ? h.eq + h.ea - 11 * (sl.p + sl.q) : h.e2 - 11 * sl.p);
+}
+__host__ __device__ inline int gram_ax(int T) { return (T + 1) >> 1; }      // query-side exponent; centre side: T - ax
+
+// ---- pack ------------------------------------------------------------------------------------------------
+template <int BC>
+__device__ inline void gram_alpha_beta(double s2, double gscale, double& alpha, double& beta) {
+  if (BC == BC_GAUSS) { alpha = -gscale * 1.4426950408889634 * s2; beta = (double)kPhiExp; }     // P = 2^(alpha d2 + 14)
+  else if (BC == BC_IQ) { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                // P = 1 / (2^-14 (1 + d2 s2))
+  else { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                                 // P = rsqrt(2^-14 (1 + d2 s2)) = 2^7 phi
+}
+// The inverse multiquadric arrives as P = 2^7 phi here (K1h: 2^14 phi, argument 2^-28 (1 + t)): an argument scaled by 2^-28
+// would push the tail operands of the expansion -- 2^-11 and 2^-22 of the heads -- below the f16 normal range.  2^7 phi is a
+// normal f16 number down to phi = 2^-21, which an algebraically decaying basis does not reach.
+template <int BC>
+__host__ __device__ constexpr float gram_phi_scale() { return BC == BC_IMQ ? 128.0f : kPhiScale; }
+
+__device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e
+  if (!(v > 0.0)) return -40;
+  int e;
+  (void)frexp(v, &e);                                        // v = f 2^e, f in [0.5, 1)
+  return e;
+}
+
+// one block: origin, exponents, the exactness budget
+__global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
+                                                          GramHdr* __restrict__ hdr, int N, int D, int bclass,
+                                                          float gscale) {
+  __shared__ float red[1024];
+  __shared__ float r_sh[8];
+  const int tid = threadIdx.x;
+  auto block_max = [&](float v) {
+    red[tid] = v;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+      if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+      __syncthreads();
+    }
+    const float m = red[0];
+    __syncthreads();
+    return m;
+  };
+  bool finite = true;
+  for (int i = 0; i < 8; ++i) {
+    float lo = 3.0e38f, hi = -3.0e38f;
+    if (i < D)
+      for (int k = tid; k < N; k += 1024) {
+        const float c = centers[(size_t)k * D + i];
+        finite = finite && (fabsf(c) < 3.0e38f);
+        lo = fminf(lo, c); hi = fmaxf(hi, c);
+      }
+    const float mx = block_max(hi), mn = -block_max(-lo);
+    if (tid == 0) r_sh[i] = i < D ? 0.5f * mx + 0.5f * mn : 0.0f;
+  }
+  __syncthreads();
+  double cabs = 0.0, amax = 0.0, cmax = 0.0, c2max = 0.0;
+  for (int k = tid; k < N; k += 1024) {
+    const double s2 = exp(-2.0 * (double)log_sigs[k]);
+    double alpha, beta;
+    if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(s2, gscale, alpha, beta);
+    else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(s2, gscale, alpha, beta);
+    else gram_alpha_beta<BC_IMQ>(s2, gscale, alpha, beta);
+    double n2 = 0.0;
+    for (int i = 0; i < D; ++i) {
+      const double cp = (double)centers[(size_t)k * D + i] - (double)r_sh[i];
+      cabs = fmax(cabs, fabs(cp));
+      cmax = fmax(cmax, fabs(2.0 * alpha * cp));
+      n2 += cp * cp;
+    }
+    amax = fmax(amax, fabs(alpha));
+    c2max = fmax(c2max, fabs(alpha * n2 + beta));
+    finite = finite && (fabs(alpha) < 1.0e30) && (amax == amax);
+  }
+  const float fc = block_max((float)cabs), fa = block_max((float)amax), fC = block_max((float)cmax), f2 = block_max((float)c2max);
+  const float bad = block_max(finite ? 0.0f : 1.0f);
+  if (tid == 0) {
+    GramHdr h;
+    for (int i = 0; i < 8; ++i) h.r[i] = r_sh[i];
+    // the box of representable queries: the centres' box with a quarter to spare (queries beyond it take the VALU distances;
+    // the card's own bounds are NOT added: a wide gate around a compact set of centres would coarsen every head)
+    const double xm = fc;
+    h.ex = gram_exp_above(1.25 * xm * 1.0000002);
+    h.ea = gram_exp_above(fa * 1.0000002);
+    h.ec = gram_exp_above(fC * 1.0000002);
+    int dbits = 0;
+    while ((1 << dbits) < D) ++dbits;
+    h.cabs = fc; h.amax = fa; h.cmax = fC; h.c2max = f2;
+    // exactness budget of the head sum: the sum of the magnitudes of its terms -- a bound on every partial sum of the adder
+    // tree -- stays below 2^24 grid units, grid = 2^(ex + ec - 20).  |x'_i| < 2^ex is what the kernel lets through.  A coarser
+    // grid (ec + 1: heads of C one bit shorter, its tails one bit larger) buys a factor of two.
+    const double xb = ldexp(1.0, h.ex);
+    const double worst = ((double)fa * D * xb * xb + (double)D * fC * xb + (double)f2) * (1.0 + 1.0 / 256.0);
+    while (worst >= ldexp(1.0, h.ex + h.ec + 4) && h.ec < 40) ++h.ec;
+    h.eq = 2 * h.ex + dbits;
+    if (h.eq + h.ea < h.ex + h.ec) h.eq = h.ex + h.ec - h.ea;                 // Q x alpha heads on the cross grid
+    h.e2 = gram_exp_above(f2 * 1.0000002);
+    if (h.e2 < h.ex + h.ec + 1) h.e2 = h.ex + h.ec + 1;                        // second c2 head on the cross grid
+    bool ok = bad == 0.0f && fc > 0.0f && fa > 0.0f;
+    // truncation in the two tail MFMAs: at most 2^-24 of D tail products of 2^(ex + ec - 10) each -- kept below 2^-20 in u
+    ok = ok && h.ex + h.ec + dbits <= 14;
+    // f16 range of every operand: |operand| <= 2^ax resp. 2^(T - ax), heads need ax - 10 >= -24
+    const int Ts[3] = {h.ex + h.ec, h.eq + h.ea, h.e2};
+    for (int t = 0; t < 3; ++t) ok = ok && gram_ax(Ts[t]) <= 14 && Ts[t] - gram_ax(Ts[t]) <= 14 && Ts[t] >= -20;
+    ok = ok && h.ex <= 12 && h.ex >= -12;
+    h.ok = ok ? 1 : 0;
+    *hdr = h;
+  }
+}
+
+// v (|v| < 2^E) -> n0 (fixed point, grid 2^-10), n1, n2 (f16 values), v = 2^E (n0 + 2^-11 n1 + 2^-22 n2)
+__device__ inline void gram_parts_d(double v, int E, double (&n)[3]) {
+  const double a = ldexp(v, -E);
+  n[0] = rint(a * 1024.0) * (1.0 / 1024.0);
+  const double r1 = (a - n[0]) * 2048.0;
+  n[1] = (double)(_Float16)(float)r1;
+  const double r2 = (r1 - n[1]) * 2048.0;
+  n[2] = (double)(_Float16)(float)r2;
+}
+// c2: two fixed-point heads, two float tails
+__device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
+  const double a = ldexp(v, -E);
+  n[0] = rint(a * 1024.0) * (1.0 / 1024.0);
+  const double r1 = (a - n[0]) * 2048.0;
+  n[1] = rint(r1 * 1024.0) * (1.0 / 1024.0);
+  const double r2 = (r1 - n[1]) * 2048.0;
+  n[2] = (double)(_Float16)(float)r2;
+  const double r3 = (r2 - n[2]) * 2048.0;
+  n[3] = (double)(_Float16)(float)r3;
+}
+
+// one thread per (chunk, centre-in-chunk)
+template <int BC>
+__global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
+                                                        const float* __restrict__ kernel, const float* __restrict__ oscale,
+                                                        const GramHdr* __restrict__ hdr, unsigned char* __restrict__ img, int N,
+                                                        int K, int D, int O, float gscale, int nchunks) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nchunks * kF16Chunk) return;
+  const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
+  const int n = idx;
+  const bool real = n < N;
+  const GramHdr h = *hdr;
+  unsigned char* p = img + (size_t)c * kGramChunkBytes;
+  const int ct = kk >> 4, row = kk & 15;                     // centre tile, A-operand row
+  double nC[kGramDims][3], nA[3], n2[4];
+  for (int i = 0; i < kGramDims; ++i) nC[i][0] = nC[i][1] = nC[i][2] = 0.0;
+  nA[0] = nA[1] = nA[2] = 0.0;
+  n2[0] = n2[1] = n2[2] = n2[3] = 0.0;
+  if (real && h.ok) {
+    const double s2 = exp(-2.0 * (double)log_sigs[n]);       // 1/sigma^2 (flax_rbf.py:280)
+    double alpha, beta;
+    gram_alpha_beta<BC>(s2, gscale, alpha, beta);
+    double c2 = beta;
+    for (int i = 0; i < D && i < kGramDims; ++i) {
+      const double cp = (double)centers[(size_t)n * D + i] - (double)h.r[i];
+      gram_parts_d(-2.0 * alpha * cp, h.ec, nC[i]);
+      c2 += alpha * cp * cp;
+    }
+    gram_parts_d(alpha, h.ea, nA);
+    gram_parts_c2(c2, h.e2, n2);
+  } else if (h.ok) {
+    double alpha, beta;                                      // a padding centre: u = beta (P finite), its W rows are 0
+    gram_alpha_beta<BC>(1.0, gscale, alpha, beta);
+    gram_parts_c2(beta, h.e2, n2);
+  }
+  auto cval = [&](const GramSlot sl) -> _Float16 {
+    if (sl.kind == 0) return (_Float16)0.0f;
+    const int T = gram_T(h, sl);
+    const int ac = T - gram_ax(T);
+    const double v = sl.kind == 1 ? nC[sl.dim][sl.q] : (sl.kind == 2 ? nA[sl.q] : n2[sl.p]);
+    return (_Float16)(float)ldexp(v, ac);
+  };
+  _Float16* head = reinterpret_cast<_Float16*>(p + ct * 512);                  // lane (g, row): k = 4 g + j
+  for (int s = 0; s < 16; ++s) head[((s >> 2) * 16 + row) * 4 + (s & 3)] = cval(gram_head_slot(s));
+  for (int s = 0; s < 64; ++s) {
+    const int half = s >> 5, g = (s >> 3) & 3, j = s & 7;
+    _Float16* tail = reinterpret_cast<_Float16*>(p + kGramHeadBytes + (ct * 2 + half) * 1024);
+    tail[(g * 16 + row) * 8 + j] = cval(gram_tail_slot(s));
+  }
+  // W rows in the k order of the Phi x W product: centre 16 ct + 4 g + r <-> k = 8 g + 4 ct + r
+  const int g = row >> 2, j = ct * 4 + (row & 3);
+  _Float16* wh = reinterpret_cast<_Float16*>(p + kGramHeadBytes + kGramTailBytes);
+  _Float16* wl = wh + kF16WBytes / 2;
+  for (int oo = 0; oo < 16; ++oo) {
+    float w = 0.0f;
+    if (real && oo < O) w = kernel[(size_t)(n % K) * O + oo] / oscale[oo];
+    _Float16 hh, ll;
+    split_static_f16(w, hh, ll);
+    wh[(g * 16 + oo) * 8 + j] = hh;
+    wl[(g * 16 + oo) * 8 + j] = ll;
+  }
+}
+
+// Diagnosis build only (tools/build_variant.py ... -DIRBFN_GRAM_STAMPS): wave 0 of blocks 0 and 1 add up s_memtime per
+// phase of the step; no output depends on it and the regular build contains none of it.
+#ifdef IRBFN_GRAM_STAMPS
+__device__ unsigned long long g_gram_stamps[32];
+#define IRBFN_GRAM_T() __builtin_amdgcn_s_memtime()
+#else
+#define IRBFN_GRAM_T() 0ull
+#endif
+
+// ---- kernel ----------------------------------------------------------------------------------------------
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+
+// The (hi, lo) pair of f16_split.h in three instructions per value instead of four: hi = the packed round-toward-zero
+// conversion itself (the leading 11 bits of P wherever P is a normal f16 number), lo = 2^11 (P - hi) as one v_fma_mix_f32
+// that reads hi as the f16 number it is: fma(hi, -2^11, 2^11 P) is exact (every term a multiple of the last bit of P).
+// (v_pk_add_f32 / v_pk_mul_f32 for the subtraction and the gain: measured slower -- packed f32 VALU costs more than the two
+// plain instructions it replaces, MI355X_MICROARCH.md constants table.)
+__device__ __forceinline__ void split_pair_mix(float p0, float p1, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+  const float q0 = p0 * kLoGain, q1 = p1 * kLoGain;
+  float d0, d1;
+  const float ng = -kLoGain;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "s"(ng), "v"(q0));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "s"(ng), "v"(q1));
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+}
+
+// the step's 16 transcendentals back to back (rbf_forward.h, trans_block), from the MFMA result registers into fresh ones
+template <int BC>
+__device__ __forceinline__ void trans16(const f4_t (&u)[2][2], float (&o)[16]) {
+#define IRBFN_T8(OP, T)                                                                                                          \
+  asm volatile(OP " %0, %8\n " OP " %1, %9\n " OP " %2, %10\n " OP " %3, %11\n " OP " %4, %12\n " OP " %5, %13\n " OP " %6, %14\n " OP     \
+               " %7, %15" IRBFN_T8_TAIL##T                                                                                       \
+               : "=&v"(o[8 * T]), "=&v"(o[8 * T + 1]), "=&v"(o[8 * T + 2]), "=&v"(o[8 * T + 3]), "=&v"(o[8 * T + 4]),           \
+                 "=&v"(o[8 * T + 5]), "=&v"(o[8 * T + 6]), "=&v"(o[8 * T + 7])                                                   \
+               : "v"(u[T][0][0]), "v"(u[T][0][1]), "v"(u[T][0][2]), "v"(u[T][0][3]), "v"(u[T][1][0]), "v"(u[T][1][1]),           \
+                 "v"(u[T][1][2]), "v"(u[T][1][3]));
+#define IRBFN_T8_TAIL0 ""
+#define IRBFN_T8_TAIL1 "\n s_nop 7"
+  if constexpr (BC == BC_GAUSS) { IRBFN_T8("v_exp_f32_e32", 0) IRBFN_T8("v_exp_f32_e32", 1) }
+  else if constexpr (BC == BC_IQ) { IRBFN_T8("v_rcp_f32_e32", 0) IRBFN_T8("v_rcp_f32_e32", 1) }
+  else { IRBFN_T8("v_rsq_f32_e32", 0) IRBFN_T8("v_rsq_f32_e32", 1) }
+#undef IRBFN_T8
+#undef IRBFN_T8_TAIL0
+#undef IRBFN_T8_TAIL1
+}
+
+struct GramArgs {
+  F16Args f;                              // x, img = K1h's image (records of the VALU path), oscale, bias, out, gate, B, ...
+  const unsigned char* __restrict__ gimg; // [nchunks][kGramChunkBytes]
+  const GramHdr* __restrict__ hdr;
+};
+
+// |v| < 2^E given as vh + vl -> normalised parts (float), as gram_parts_d
+__device__ __forceinline__ void gram_parts_f(float vh, float vl, float inv, float (&n)[3]) {
+  const float a = vh * inv, b = vl * inv;                    // exact (power of two)
+  n[0] = __builtin_rintf(a * 1024.0f) * (1.0f / 1024.0f);
+  const float r1 = ((a - n[0]) + b) * 2048.0f;               // a - n0 is exact
+  n[1] = (float)(_Float16)r1;
+  const float r2 = (r1 - n[1]) * 2048.0f;
+  n[2] = (float)(_Float16)r2;
+}
+
+template <int DC, int BC, bool ROLL>
+__device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl, int mode, unsigned char* lds) {
+  static_assert(DC <= kGramDims, "seven coordinate slots");
+  const F16Args& a = ga.f;
+  constexpr int RF = f16_rf(DC);
+  constexpr int CBL = f16_chunk_bytes(DC);                   // K1h's chunk image (the VALU path reads its records)
+  constexpr int CB = kGramChunkBytes;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, QG = a.QG;
+  const int slice = wave / QG, qg = wave % QG;               // the QG waves of a slice are adjacent and share its ring
+  const int g = lane >> 4, n = lane & 15;
+  const long q0 = ((long)blockIdx.x * QG + qg) * 32;
+  const GramHdr* hp = ga.hdr;
+  const int ex = hp->ex, ec = hp->ec, eq = hp->eq, ea = hp->ea, e2 = hp->e2;
+  GramHdr hx;                                                // exponents only (gram_T)
+  hx.ex = ex; hx.ec = ec; hx.eq = eq; hx.ea = ea; hx.e2 = e2;
+  long qrow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long q = q0 + t * 16 + n;
+    q = q < a.B ? q : a.B - 1;
+    qrow[t] = q < 0 ? 0 : q;
+  }
+  // ---- query-side operands: B[k = slot][column = query]
+  h4_t bhd[2];
+  h8_t btl[2][2];
+  bool bad = hp->ok == 0;
+  {
+    const float xinv = __builtin_ldexpf(1.0f, -ex), qinv = __builtin_ldexpf(1.0f, -eq);
+    const float xlim = __builtin_ldexpf(1.0f, ex) * 0.999f, qlim = __builtin_ldexpf(1.0f, eq) * 0.999f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float nx[kGramDims][3], nq[3];
+      float qh = 0.0f, ql = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kGramDims; ++i) {
+        if (i < DC) {
+          const float xv = i < a.Dreal ? a.x[qrow[t] * a.Dreal + i] : 0.0f;
+          const float rr = -hp->r[i];
+          const float sh = xv + rr;                          // TwoSum: x' = sh + sl exactly
+          const float bb = sh - xv;
+          const float sl = (xv - (sh - bb)) + (rr - bb);
+          bad = bad || !(__builtin_fabsf(sh) < xlim);        // NaN / Inf / outside the box
+          gram_parts_f(sh, sl, xinv, nx[i]);
+          const float ph = sh * sh;                          // Q += x'^2 in double-float
+          const float pl = __builtin_fmaf(sh, sh, -ph) + 2.0f * sh * sl;
+          const float th = qh + ph;
+          const float tb = th - qh;
+          ql += ((qh - (th - tb)) + (ph - tb)) + pl;
+          qh = th;
+        } else {
+          nx[i][0] = nx[i][1] = nx[i][2] = 0.0f;
+        }
+      }
+      bad = bad || !(qh < qlim);
+      gram_parts_f(qh, ql, qinv, nq);
+      auto xval = [&](const GramSlot sl) -> float {
+        if (sl.kind == 0) return 0.0f;
+        const float sc = __builtin_ldexpf(1.0f, gram_ax(gram_T(hx, sl)));
+        return sl.kind == 1 ? nx[sl.dim][sl.p] * sc : (sl.kind == 2 ? nq[sl.p] * sc : sc);
+      };
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = xval(gram_head_slot(j)), v1 = xval(gram_head_slot(4 + j)), v2 = xval(gram_head_slot(8 + j)),
+                    v3 = xval(gram_head_slot(12 + j));
+        bhd[t][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v0 = xval(gram_tail_slot(32 * hf + j)), v1 = xval(gram_tail_slot(32 * hf + 8 + j)),
+                      v2 = xval(gram_tail_slot(32 * hf + 16 + j)), v3 = xval(gram_tail_slot(32 * hf + 24 + j));
+          btl[t][hf][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
+        }
+    }
+  }
+  const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;     // wave-uniform: the VALU distances for these 32 queries
+
+  const int c0 = (int)((long)a.nchunks * slice / S), c1 = (int)((long)a.nchunks * (slice + 1) / S);
+  const int na = c1 - c0;
+  int nsteps = 0;                                            // every wave of the block walks the longest slice (barriers)
+  for (int s2 = 0; s2 < S; ++s2) {
+    const int m = (int)((long)a.nchunks * (s2 + 1) / S) - (int)((long)a.nchunks * s2 / S);
+    nsteps = m > nsteps ? m : nsteps;
+  }
+  // Ring of three chunk images per slice: during step i the waves read the distance operands of chunk i + 1 and the W
+  // operands of chunk i while chunk i + 2 lands; one barrier per step, at its end.
+  unsigned char* ring = lds + (size_t)slice * 3 * CB;
+  constexpr int NVI = CB / 1024;                             // 7 wave-instructions per chunk image
+  auto stage = [&](int k, int buf) {                         // chunk c0 + k of the slice -> ring slot buf; the QG waves share the copy
+    if (k >= na) return;
+    const unsigned char* gp = ga.gimg + (size_t)(c0 + k) * CB + lane * 16;
+    unsigned char* dst = ring + buf * CB;
+    for (int v = qg; v < NVI; v += QG)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gp + v * 1024), (lptr_t)(dst + v * 1024), 16, 0, 0);
+  };
+  auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto next3 = [&](int b3) { return b3 == 2 ? 0 : b3 + 1; };
+
+  f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A1: ph * wh
+  f4_t acl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A2: pls * wh + ph * wls
+  // the argument of the transcendental for the 2 x 2 tiles of chunk `buf`: head sum (exact), then the tails
+  auto distances = [&](const unsigned char* buf, f4_t (&u)[2][2]) {
+    h4_t ahd[2];
+    h8_t atl[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      ahd[ct] = *reinterpret_cast<const h4_t*>(buf + ct * 512 + lane * 8);
+      atl[ct][0] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 0) * 1024 + lane * 16);
+      atl[ct][1] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 1) * 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        u[t][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahd[ct], bhd[t], f4_t{0, 0, 0, 0}, 0, 0, 0);   // exact head sum
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          u[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(atl[ct][hf], btl[t][hf], u[t][ct], 0, 0, 0);
+  };
+  // transcendental, hi / lo split and Phi x W of the 16 pairs in t16 with the W operands of chunk `buf`
+  auto products = [&](float (&t16)[16], const unsigned char* buf, auto pre) {
+    const h8_t bh = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + kGramTailBytes + lane * 16);
+    const h8_t bl = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + kGramTailBytes + kF16WBytes + lane * 16);
+    pre(t16);                                                // P = 2^kPhiExp * phi for the step's 16 pairs
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      unsigned wh[4], wl[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) split_pair_mix(t16[t * 8 + 2 * jj], t16[t * 8 + 2 * jj + 1], wh[jj], wl[jj]);
+      const h8_t ah = __builtin_bit_cast(h8_t, u4_t{wh[0], wh[1], wh[2], wh[3]});
+      const h8_t al = __builtin_bit_cast(h8_t, u4_t{wl[0], wl[1], wl[2], wl[3]});
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+      acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acl[t], 0, 0, 0);
+      acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acl[t], 0, 0, 0);
+    }
+  };
+
+  stage(0, 0);
+  stage(1, 1);
+  step_barrier();                                            // chunks 0 and 1 are there
+  stage(2, 2);
+  if (!wave_bad) {
+    // two steps per trip: the distances of chunk i + 1 are issued in front of the VALU work on chunk i
+    f4_t ua[2][2], ub[2][2];
+    if (na > 0) distances(ring, ua);
+    int b0 = 0;                                              // ring slot of chunk i
+    [[maybe_unused]] unsigned long long tph[5] = {0, 0, 0, 0, 0};
+    auto one_step = [&](int i, f4_t (&ucur)[2][2], f4_t (&unxt)[2][2]) {
+      const int b1 = next3(b0);
+      [[maybe_unused]] const unsigned long long t0 = IRBFN_GRAM_T();
+      if (i + 1 < na) distances(ring + b1 * CB, unxt);       // issued in front of the VALU work on chunk i
+      if (i < na) {
+        float t16[16];
+        products(t16, ring + b0 * CB, [&](float (&o)[16]) { trans16<BC>(ucur, o); });
+      }
+      [[maybe_unused]] const unsigned long long t2 = IRBFN_GRAM_T();
+      step_barrier();                                        // chunk i + 2 is there; everybody has left chunk i
+      [[maybe_unused]] const unsigned long long t3 = IRBFN_GRAM_T();
+      stage(i + 3, b0);
+      [[maybe_unused]] const unsigned long long t4 = IRBFN_GRAM_T();
+#ifdef IRBFN_GRAM_STAMPS
+      tph[1] += t2 - t0; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += 1;
+#endif
+      b0 = b1;
+    };
+    for (int i = 0; i < nsteps; i += 2) {
+      one_step(i, ua, ub);
+      if (i + 1 < nsteps) one_step(i + 1, ub, ua);
+    }
+#ifdef IRBFN_GRAM_STAMPS
+    if (blockIdx.x < 2 && tid == 0)
+      for (int k = 0; k < 5; ++k) g_gram_stamps[blockIdx.x * 8 + k] = tph[k];
+#endif
+  } else {
+    // a query of this wave lies outside the representable box (or is not finite): K1h's distances for its 32 queries,
+    // same barriers and the same share of the copies
+    int b0 = 0;
+    for (int i = 0; i < nsteps; ++i) {
+      if (i < na) {
+        float t16[16];
+        const float* recs = reinterpret_cast<const float*>(a.img + (size_t)(c0 + i) * CBL);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float xq[DC];
+#pragma unroll
+          for (int d = 0; d < DC; ++d) xq[d] = d < a.Dreal ? a.x[qrow[t] * a.Dreal + d] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float* rp = recs + ((j >> 2) * 16 + 4 * g + (j & 3)) * RF;
+            float r2 = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DC; ++d) {
+              const float df = xq[d] - rp[d];                // flax_rbf.py:280
+              r2 = __builtin_fmaf(df, df, r2);
+            }
+              float arg = f16_arg<BC>(r2, rp[RF - 1]);
+            if constexpr (BC == BC_IMQ) arg *= kPhiScale;    // 2^7 phi here (gram_phi_scale), K1h's records are scaled for 2^14 phi
+            t16[t * 8 + j] = arg;
+          }
+        }
+        products(t16, ring + b0 * CB, [&](float (&o)[16]) { trans_block<BC, 16>(o); });
+      }
+      step_barrier();
+      stage(i + 3, b0);
+      b0 = next3(b0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], kLoScale, acc[t][r]);   // A1 + 2^-11 A2
+
+  // ---- smooth region gate of the single region (model.py:42-95), one value per query
+  const GateTables gt = a.gate;
+  float gam[2] = {0.0f, 0.0f};
+  if (slice == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;              // model.py:70
+#pragma unroll
+      for (int d = 0; d < DC; ++d)
+        if (d < gt.nsplit && gt.n_ranges > 0) {
+          const int e = d * gt.max_ranges + gt.dim_ranges[d];
+          gv *= gate_factor(a.x[qrow[t] * a.Dreal + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+        }
+      gam[t] = gv;
+    }
+  }
+  narrow_epilogue<ROLL>(a, rl, mode, lds, acc, gam, S, slice, qg, q0, 1.0f / (gram_phi_scale<BC>() * kWScale));
+}
+
+template <int DC, int BC>
+__global__ __launch_bounds__(1024, IRBFN_GRAM_WAVES) void rbf_fwd_f16gram(const GramArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  gram_body<DC, BC, false>(ga, F16Roll{}, -1, lds);
+}
+
+// the planning tick of a narrow net in one launch (forward + sign flip + roll-out; irbfn_planner.py:203-212)
+template <int DC, int BC>
+__global__ __launch_bounds__(1024, IRBFN_GRAM_WAVES) void rbf_tick_f16gram(const GramArgs ga, const F16Roll rl, const int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  gram_body<DC, BC, true>(ga, rl, mode, lds);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+bool gram_eligible(const irbfn_net* net) {
+  return f16_eligible(net) && net->O <= 16 && net->DC <= kGramDims;
+}
+
+size_t gram_image_bytes(const irbfn_net* net) {
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  return (size_t)nchunks * kGramChunkBytes;
+}
+
+size_t gram_header_bytes() { return sizeof(GramHdr); }
+
+// after K1h's pack (needs its column scales).  Reads the header back (one small synchronous copy): whether this net
+// runs on K1g is a property of its parameters.
+int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  GramHdr* hdr = reinterpret_cast<GramHdr*>(net->gram_hdr);
+  hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(1024), 0, s, centers, log_sigs, hdr, net->N, net->D,
+                     net->bclass, gauss_scale(net->basis));
+  IRBFN_HIP_CHECK(hipGetLastError());
+  const int total = nchunks * kF16Chunk;
+  const dim3 grid((total + 255) / 256), block(256);
+  const float gs = gauss_scale(net->basis);
+  switch (net->bclass) {
+    case BC_GAUSS: hipLaunchKernelGGL((gram_pack_kernel<BC_GAUSS>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
+    case BC_IQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
+    case BC_IMQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IMQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+  IRBFN_HIP_CHECK(hipGetLastError());
+  GramHdr h;
+  IRBFN_HIP_CHECK(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+  IRBFN_HIP_CHECK(hipStreamSynchronize(s));
+  net->gram_ok = h.ok;
+  net->gram_exp[0] = h.ex; net->gram_exp[1] = h.ec; net->gram_exp[2] = h.eq; net->gram_exp[3] = h.ea; net->gram_exp[4] = h.e2;
+  return IRBFN_OK;
+}
+
+#ifdef IRBFN_GRAM_STAMPS
+extern "C" int irbfn_debug_gram_stamps(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_gram_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
+
+template <int DC>
+static int launch_gram_bc(const GramArgs& a, int bc, int grid, int block, size_t lds, hipStream_t s) {
+#define IRBFN_GCASE(BCV)                                                                                      \
+  case BCV: {                                                                                                 \
+    auto k = rbf_fwd_f16gram<DC, BCV>;                                                                        \
+    if (lds > 48 * 1024) {                                                                                    \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }                               \
+    }                                                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, s, a);                                                \
+    break;                                                                                                    \
+  }
+  switch (bc) {
+    IRBFN_GCASE(BC_GAUSS)
+    IRBFN_GCASE(BC_IQ)
+    IRBFN_GCASE(BC_IMQ)
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+#undef IRBFN_GCASE
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// S centre slices x QG query groups of 32 per block (S * QG <= 8 waves)
+int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, hipStream_t s) {
+  if (!net->gram_img || !net->f16_img || !gram_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  if (S < 1 || QG < 1 || S * QG > 16 || S > nchunks) return IRBFN_ERR_BAD_ARG;
+  GramArgs a;
+  a.f.x = x; a.f.img = net->f16_img; a.f.oscale = net->f16_oscale; a.f.bias = net->bias; a.f.out = out; a.f.gate = net->gate();
+  a.f.B = (long)B; a.f.Dreal = net->D; a.f.O = net->O; a.f.nchunks = nchunks; a.f.S = S; a.f.QG = QG;
+  a.gimg = net->gram_img;
+  a.hdr = reinterpret_cast<const GramHdr*>(net->gram_hdr);
+  const int waves = S * QG;
+  const size_t ring = (size_t)S * 3 * kGramChunkBytes;
+  const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
+  const size_t lds = ring > red ? ring : red;
+  if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
+  const long groups = (B + 31) / 32;
+  const int grid = (int)((groups + QG - 1) / QG);
+  int rc;
+  switch (net->DC) {
+    case 3: rc = launch_gram_bc<3>(a, net->bclass, grid, waves * 64, lds, s); break;
+    case 4: rc = launch_gram_bc<4>(a, net->bclass, grid, waves * 64, lds, s); break;
+    case 7: rc = launch_gram_bc<7>(a, net->bclass, grid, waves * 64, lds, s); break;
+    default: rc = IRBFN_ERR_UNSUPPORTED;
+  }
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16gram<D=%d,BC=%d,S=%d,QG=%d>", net->DC, net->bclass, S, QG);
+    net->last_grid = grid;
+    net->last_block = waves * 64;
+  }
+  return rc;
+}
+
+template <int DC>
+static int launch_tick_gram_bc(const GramArgs& a, const F16Roll& rl, int mode, int bc, int grid, int block, size_t lds, hipStream_t s) {
+#define IRBFN_GCASE(BCV)                                                                                      \
+  case BCV: {                                                                                                 \
+    auto k = rbf_tick_f16gram<DC, BCV>;                                                                       \
+    if (lds > 48 * 1024) {                                                                                    \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      if (e != hipSuccess) { g_last_hip_error = (int)e; return IRBFN_ERR_HIP; }                               \
+    }                                                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, s, a, rl, mode);                                      \
+    break;                                                                                                    \
+  }
+  switch (bc) {
+    IRBFN_GCASE(BC_GAUSS)
+    IRBFN_GCASE(BC_IQ)
+    IRBFN_GCASE(BC_IMQ)
+    default: return IRBFN_ERR_UNSUPPORTED;
+  }
+#undef IRBFN_GCASE
+  IRBFN_HIP_CHECK(hipGetLastError());
+  return IRBFN_OK;
+}
+
+// The one-launch planning tick of a narrow net on K1g (rbf_tick_f16gram): same conditions as K1h's (launch_tick_f16_narrow),
+// and the parameters fit the expansion.  IRBFN_ERR_UNSUPPORTED: no instance -> the caller takes another path
+int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0, const DynParams& dp,
+                            float* controls, float* states, int64_t B, int T, hipStream_t s) {
+  if (net->opt[IRBFN_OPT_FWD_KERNEL] != IRBFN_FWD_AUTO && net->opt[IRBFN_OPT_FWD_KERNEL] != IRBFN_FWD_K1G) return IRBFN_ERR_UNSUPPORTED;
+  if (!gram_preferred(net, B) || net->DC != 7) return IRBFN_ERR_UNSUPPORTED;
+  if (net->opt[IRBFN_OPT_TICK_FUSED] == 0 || net->O != 2 * T || T > kTickNarrowT) return IRBFN_ERR_UNSUPPORTED;
+  if (mode != IRBFN_ROLLOUT_ST_SELECT && mode != IRBFN_ROLLOUT_ST_KS && mode != IRBFN_ROLLOUT_FULLINT) return IRBFN_ERR_UNSUPPORTED;
+  int S, QG;
+  gram_geometry(net, B, &S, &QG);
+  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
+  const int waves = S * QG;
+  const size_t ring = (size_t)S * 3 * kGramChunkBytes;
+  const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32 + (size_t)QG * 32 * (kTickNarrowCP + kTickNarrowSP)) * sizeof(float);
+  const size_t lds = ring > red ? ring : red;
+  if (lds > 160 * 1024 || S > nchunks) return IRBFN_ERR_UNSUPPORTED;
+  GramArgs a;
+  a.f.x = x; a.f.img = net->f16_img; a.f.oscale = net->f16_oscale; a.f.bias = net->bias; a.f.out = controls; a.f.gate = net->gate();
+  a.f.B = (long)B; a.f.Dreal = net->D; a.f.O = net->O; a.f.nchunks = nchunks; a.f.S = S; a.f.QG = QG;
+  a.gimg = net->gram_img;
+  a.hdr = reinterpret_cast<const GramHdr*>(net->gram_hdr);
+  F16Roll rl;
+  rl.state0 = state0; rl.states = states; rl.mirror = mirror; rl.T = T; rl.wlds = 0; rl.dp = dp;
+  const long groups = (B + 31) / 32;
+  const int grid = (int)((groups + QG - 1) / QG);
+  const int rc = launch_tick_gram_bc<7>(a, rl, mode, net->bclass, grid, waves * 64, lds, s);
+  if (rc == IRBFN_OK) {
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_tick_f16gram<D=%d,BC=%d,MODE=%d,S=%d,QG=%d>", net->DC, net->bclass, mode, S, QG);
+    net->last_grid = grid;
+    net->last_block = waves * 64;
+  }
+  return rc;
+}
+
+}  // namespace irbfn

@@ -34,7 +34,8 @@ def test_single_gpu_line(gpu):
     rf = j["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
-    assert rf["kernel"].startswith("rbf_fwd_f16mfma<") and "TERMS=3" in rf["kernel"]      # the product path, full precision
+    # the product path, full precision: K1g (distances and Phi x W on the matrix cores) or K1h with (hi, lo) operand pairs
+    assert rf["kernel"].startswith("rbf_fwd_f16gram<") or (rf["kernel"].startswith("rbf_fwd_f16mfma<") and "TERMS=3" in rf["kernel"])
     assert {"valu_f32", "mfma_f16"} <= set(rf["by_unit"]) and rf["by_unit"]["mfma_f16"]["frac"] < 1.0
     cb = j["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0

@@ -47,7 +47,7 @@ def test_cfg2_forward_full_batch(gpu):
     cfg, P, x = configs.model_card(2), configs.synth_params(2), configs.synth_queries(2)
     net = WCRBFNet.from_config(cfg)
     out = net.apply(P, torch.from_numpy(x).cuda())
-    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<D=7,BC=0,TERMS=3")       # the product path
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<D=7,BC=0")               # the product path
     got = out.cpu().numpy().astype(np.float64)
     ref = co.wcrbf_forward(cfg, P, x, np.float64)
     scale = _terms_scale(cfg, P, x)
@@ -161,7 +161,7 @@ def test_cfg5_forward_full_batch(gpu):
     net = WCRBFNet.from_config(cfg)
     xt = torch.from_numpy(x).cuda()
     out = net.apply(P, xt)
-    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<D=7,BC=2,TERMS=3")
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<D=7,BC=2")
     rows = np.arange(0, 1 << 20, 512)
     ref = co.wcrbf_forward(cfg, P, x[rows], np.float64)
     scale = _terms_scale(cfg, P, x[rows])

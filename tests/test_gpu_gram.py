@@ -1,0 +1,254 @@
+"""GPU parity of K1g (`rbf_fwd_f16gram` / `rbf_tick_f16gram`, irbfn_amd/csrc/rbf_forward_gram.hip): the narrow forward with the
+squared distances as a Gram expansion on the f16 matrix cores (exact fixed-point heads + float tails) in front of K1h's
+Phi x W.  Against the float64 oracle scaled by sum_k |phi_k W_k| (the natural error scale of the reduction), against the
+all-float32 kernel K1 and K1h, at 1e-5 relative to |ref| on ill-conditioned columns built without cancellation; queries
+outside the representable box (and non-finite ones) take K1h's distances wave by wave; parameters outside the exactness budget
+are refused."""
+import numpy as np
+import pytest
+
+from conftest import load_ckpt_fixture
+from irbfn_amd import _lib, configs
+from irbfn_amd.model import WCRBFNet
+from oracle import irbfn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = {"fwd_kernel": 0, "fwd_f16_s": 0, "fwd_f16_qg": 0}
+
+
+def _run(net, params, x, kernel=None, **opts):
+    net.set_options(fwd_kernel=_lib.FWD_K1G if kernel is None else kernel, **opts)
+    try:
+        got = net.apply(params, x)
+        name = net.last_launch()["kernel"]
+    finally:
+        net.set_options(**{k: DEFAULTS[k] for k in ["fwd_kernel", *opts]})
+    return got, name
+
+
+def _terms_scale(cfg, p64, x):
+    pa = {"params": {"rbf_list": p64["params"]["rbf_list"],
+                     "linear": {"kernel": np.abs(p64["params"]["linear"]["kernel"]), "bias": np.abs(p64["params"]["linear"]["bias"])}}}
+    return orc.wcrbfnet_apply(cfg, pa, x)
+
+
+def _card(D, K, O, basis, lo, hi, delta=20.0):
+    return {"in_features": D, "out_features": O, "num_kernels": K, "basis_func": basis, "num_regions": 1,
+            "lower_bounds": [[float(v)] for v in lo], "upper_bounds": [[float(v)] for v in hi],
+            "dimension_ranges": [[0] * D], "activation_idx": list(range(D)), "delta": [delta] * D}
+
+
+def test_gram_is_the_default_at_config_2_and_as_accurate_as_the_float32_kernel(gpu):
+    cfg, params = configs.model_card(2), configs.synth_params(2)
+    net = WCRBFNet.from_config(cfg)
+    B = 4096 + 37                                    # ragged tail
+    x = configs.synth_queries(2, B=B)
+    auto = net.apply(params, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<D=7,BC=0"), net.last_launch()
+    got, name = _run(net, params, x)
+    assert name.startswith("rbf_fwd_f16gram<") and np.array_equal(got, auto)
+    p64 = orc.cast_params(params, np.float64)
+    x64 = x.astype(np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x64)
+    scale = _terms_scale(cfg, p64, x64)
+    err = np.abs(got - ref) / scale
+    k1, nm = _run(net, params, x, kernel=_lib.FWD_K1)
+    assert nm.startswith("rbf_fwd_qlane")
+    k1h, nm = _run(net, params, x, kernel=_lib.FWD_K1H)
+    assert nm.startswith("rbf_fwd_f16mfma<")
+    err_k1, err_h = np.abs(k1 - ref) / scale, np.abs(k1h - ref) / scale
+    print(f"K1g max/mean err {err.max():.2e}/{err.mean():.2e}   K1h {err_h.max():.2e}/{err_h.mean():.2e}   K1 {err_k1.max():.2e}/{err_k1.mean():.2e}")
+    # float32-equivalent: no worse than the float32 FMA-chain kernel on the same inputs
+    # (the mean carries the truncation of the tail products on top: measured 1.9e-8 against 1.15e-8 for K1, 1.24e-8 for K1h)
+    assert err.max() <= 3e-6 and err.max() <= 2.0 * err_k1.max() and err.mean() <= 2.5 * err_k1.mean(), (err.max(), err_k1.max())
+    assert (np.abs(got - k1) / scale).max() <= 1e-5
+    # every (S, QG) geometry gives the same answer up to the slice summation order; the answer does not depend on the run
+    for S, QG in ((1, 8), (2, 4), (2, 8), (1, 4), (4, 1), (1, 1)):
+        g2, nm = _run(net, params, x, fwd_f16_s=S, fwd_f16_qg=QG)
+        assert f"S={S},QG={QG}" in nm
+        assert (np.abs(g2 - ref) / scale).max() <= 3e-6, (S, QG)
+        g3, _ = _run(net, params, x, fwd_f16_s=S, fwd_f16_qg=QG)
+        assert np.array_equal(g2, g3)
+
+
+@pytest.mark.parametrize("B", [65, 100, 2500])
+def test_gram_on_the_reference_s_trained_single_region_planner(gpu, B):
+    """Trained single-region net of the reference (gaussian, O = 10; K = 1000 is not a multiple of the 32-centre chunk; bounds
+    make gamma != 1 near the edges)."""
+    cfg, params, x0, out64, *_ = load_ckpt_fixture("dnmpc_1regions_newdata_oldintloss_nomirror_highk")
+    net = WCRBFNet.from_config(cfg)
+    ns = len(cfg["activation_idx"])
+    lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)])
+    hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+    x = np.random.default_rng(B).uniform(lo - 0.02, hi + 0.02, size=(B, cfg["in_features"])).astype(np.float32)
+    x[:64] = x0.astype(np.float32)
+    p32 = orc.cast_params(params, np.float32)
+    got, name = _run(net, p32, x)
+    assert name.startswith("rbf_fwd_f16gram<"), name
+    p64 = orc.cast_params(p32, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    assert (np.abs(got - ref) / scale).max() <= 2e-6
+    gam = orc.region_activation(x.astype(np.float64), cfg["num_regions"], len(cfg["activation_idx"]), cfg["lower_bounds"],
+                                cfg["upper_bounds"], cfg["delta"], cfg["dimension_ranges"])
+    assert gam.min() < 0.9 and gam.max() > 0.99      # the gate is exercised
+
+
+@pytest.mark.parametrize("D,K,O,basis", [(3, 256, 5, "gaussian"), (4, 96, 16, "inverse_multiquadric"), (7, 200, 2, "inverse_quadratic"),
+                                         (7, 33, 1, "gaussian_wide"), (5, 64, 7, "inverse_multiquadric"), (2, 50, 3, "gaussian_wider"),
+                                         (6, 1000, 10, "gaussian")])
+def test_gram_shapes_and_bases(gpu, D, K, O, basis):
+    rng = np.random.default_rng(D * 100 + K)
+    lo, hi = -np.ones(D) * 2, np.ones(D) * 3
+    cfg = _card(D, K, O, basis, lo, hi)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(lo - 1, hi + 1, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": rng.uniform(-0.5, 1.5, size=(1, K)).astype(np.float32)},
+                         "linear": {"kernel": (rng.normal(size=(K, O)) * rng.choice([1e-3, 1.0, 300.0], size=(1, O))).astype(np.float32),
+                                    "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    for B in (1000, 70):
+        x = rng.uniform(lo, hi, size=(B, D)).astype(np.float32)
+        got, name = _run(net, params, x)
+        assert name.startswith("rbf_fwd_f16gram<"), name
+        p64 = orc.cast_params(params, np.float64)
+        ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+        scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+        assert (np.abs(got - ref) / scale).max() <= 2e-6, B
+
+
+@pytest.mark.parametrize("basis", ["gaussian", "inverse_quadratic", "inverse_multiquadric"])
+@pytest.mark.parametrize("case", ["outlier_far_centre", "six_decades", "queries_on_small_weight_centres", "columns_1e-6_to_1e6"])
+def test_gram_ill_conditioned_columns(gpu, case, basis):
+    """The adversarial columns of tests/test_gpu_f16.py::test_forward_f16_ill_conditioned_columns on K1g: positive weights (no
+    cancellation: |ref| is the error scale), 1e-5 relative to |ref| and float32-grade (as good as the all-float32 K1).  The
+    queries sitting ON centres make the expansion cancel completely -- the case the exact head sum is for.  (With the gaussian
+    the far outlier centre at 60 widens the box of the expansion past its budget: that net stays on K1h.)"""
+    from test_gpu_f16 import _cond_net
+    K, O = 512, 10
+    rng, cfg, centers, log_sigs = _cond_net(K, O, basis, seed=len(case))
+    B = 2048 + 5
+    x = rng.uniform(0.0, 4.0, size=(B, 7)).astype(np.float32)
+    W = np.abs(rng.normal(size=(K, O))) + 0.05
+    if case == "outlier_far_centre":
+        centers[0, 3] = 60.0
+        log_sigs[0, 3] = -0.5
+        W[3, :] = 1.0e4
+    elif case == "six_decades":
+        W = 10.0 ** rng.uniform(-3, 3, size=(K, O))
+    elif case == "queries_on_small_weight_centres":
+        W = 10.0 ** rng.uniform(-3, 3, size=(K, O))
+        small = np.argsort(W.max(axis=1))[:64]
+        x[:1024] = centers[0, small[rng.integers(0, 64, size=1024)]] + rng.normal(0, 0.02, size=(1024, 7)).astype(np.float32)
+        x[:256] = centers[0, small[rng.integers(0, 64, size=256)]]          # exactly ON a centre
+        log_sigs[0, small] = -1.5
+    else:
+        W = W * 10.0 ** np.linspace(-6, 6, O)[None, :]
+    params = {"params": {"rbf_list": {"centers": centers, "log_sigs": log_sigs},
+                         "linear": {"kernel": W.astype(np.float32), "bias": np.zeros(O, np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    got = net.apply(params, x)
+    name = net.last_launch()["kernel"]
+    if case == "outlier_far_centre":                        # the gaussian's 2 alpha c' leaves the budget, the algebraic bases' do not
+        assert name.startswith("rbf_fwd_f16mfma<" if basis == "gaussian" else "rbf_fwd_f16gram<"), name
+    else:
+        assert name.startswith("rbf_fwd_f16gram<"), name
+    k1, _ = _run(net, params, x, kernel=_lib.FWD_K1)
+    ref = orc.wcrbfnet_apply(cfg, orc.cast_params(params, np.float64), x.astype(np.float64))
+    assert (ref > 0).all()
+    rel, rel_k1 = np.abs(got - ref) / ref, np.abs(k1 - ref) / ref
+    print(f"{case}/{basis}: {name.split('<')[0]} max rel {rel.max():.2e} (K1 {rel_k1.max():.2e}), median {np.median(rel):.2e}")
+    assert rel.max() <= 1e-5, (case, basis, rel.max(), rel_k1.max())        # north-star: 1e-5 relative to |ref|
+    assert rel.max() <= max(3e-6, 2.5 * rel_k1.max())                        # and float32-grade: as good as K1
+
+
+def test_gram_narrow_widths_far_from_the_origin(gpu):
+    """What the exact head sum is for: centres and queries far from the expansion's origin (|c'| up to 6 in units where the
+    widths are 0.45 .. 1), queries within a fraction of a width of a centre.  The terms of the expansion reach 2^10 here while u
+    stays below 1: a float32-accumulated expansion would be off by 2^-24 * 2^10 = 6e-5 in u; the result must stay at the
+    float32 kernel's level."""
+    rng = np.random.default_rng(5)
+    D, K, O, B = 7, 256, 4, 4096
+    lo, hi = -6.0 * np.ones(D), 6.0 * np.ones(D)
+    cfg = _card(D, K, O, "gaussian", lo, hi, delta=100.0)
+    centers = rng.uniform(lo, hi, size=(1, K, D)).astype(np.float32)
+    centers[0, :16] = np.sign(rng.normal(size=(16, D))) * rng.uniform(5.5, 6.0, size=(16, D))        # corners
+    log_sigs = rng.uniform(-0.8, 0.0, size=(1, K)).astype(np.float32)
+    W = (np.abs(rng.normal(size=(K, O))) + 0.1).astype(np.float32)
+    x = (centers[0, rng.integers(0, K, size=B)] + rng.normal(0, 0.15, size=(B, D))).astype(np.float32)
+    x = np.clip(x, lo + 0.05, hi - 0.05).astype(np.float32)
+    params = {"params": {"rbf_list": {"centers": centers, "log_sigs": log_sigs}, "linear": {"kernel": W, "bias": np.zeros(O, np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    got, name = _run(net, params, x)
+    assert name.startswith("rbf_fwd_f16gram<"), name
+    k1, _ = _run(net, params, x, kernel=_lib.FWD_K1)
+    ref = orc.wcrbfnet_apply(cfg, orc.cast_params(params, np.float64), x.astype(np.float64))
+    keep = ref > 1e-3                                                                                  # outputs that see a centre
+    rel, rel_k1 = (np.abs(got - ref) / ref)[keep], (np.abs(k1 - ref) / ref)[keep]
+    print(f"far from the origin: K1g max rel {rel.max():.2e} mean {rel.mean():.2e}   K1 {rel_k1.max():.2e} mean {rel_k1.mean():.2e}")
+    assert keep.mean() > 0.5 and rel.max() <= 1e-5 and rel.max() <= 10.0 * rel_k1.max() + 3e-6
+
+
+def test_gram_queries_outside_the_box_take_the_float32_distances(gpu):
+    """A wave with a query outside the representable box (here: 1e3 and 1e6 away, +-Inf, NaN) computes its 32 queries' distances
+    on the VALU from K1h's records (K1h's arithmetic; the summation order over the centres is K1g's): NaN propagates like jnp,
+    Inf gives bias (gamma = 0, phi = 0), every other wave is untouched."""
+    cfg, params = configs.model_card(2), configs.synth_params(2)
+    net = WCRBFNet.from_config(cfg)
+    B = 32 * 40 + 5
+    x = configs.synth_queries(2, B=B)
+    clean, _ = _run(net, params, x)
+    xb = x.copy()
+    xb[3, 2] = 1.0e3
+    xb[40, 0] = -1.0e6
+    xb[70, 5] = np.inf
+    xb[100, 1] = -np.inf
+    xb[130, 6] = np.nan
+    xb[B - 1, 3] = 50.0                                   # in the ragged tail group
+    got, name = _run(net, params, xb)
+    assert name.startswith("rbf_fwd_f16gram<")
+    k1h, _ = _run(net, params, xb, kernel=_lib.FWD_K1H)
+    bad_groups = sorted({r // 32 for r in (3, 40, 70, 100, 130, B - 1)})
+    rows_bad = np.concatenate([np.arange(g * 32, min((g + 1) * 32, B)) for g in bad_groups])
+    rows_ok = np.setdiff1d(np.arange(B), rows_bad)
+    assert np.array_equal(got[rows_ok], clean[rows_ok])
+    p64 = orc.cast_params(params, np.float64)
+    fin = rows_bad[np.isfinite(xb[rows_bad]).all(axis=1)]
+    ref = orc.wcrbfnet_apply(cfg, p64, xb[fin].astype(np.float64))
+    scale = _terms_scale(cfg, p64, xb[fin].astype(np.float64)) + 1e-30
+    assert (np.abs(got[fin] - ref) / scale).max() <= 3e-6 and (np.abs(got[fin] - k1h[fin]) / scale).max() <= 3e-6
+    assert np.isnan(got[130]).all() and np.isfinite(got[[3, 40, 70, 100, B - 1]]).all()
+    bias = np.asarray(params["params"]["linear"]["bias"], np.float32)
+    assert np.allclose(got[70], bias, atol=1e-6) and np.allclose(got[100], bias, atol=1e-6)
+
+
+def test_gram_refuses_parameters_outside_its_budget(gpu):
+    """Widths of 1e-3 next to centres spread over +-5: alpha |c'|^2 ~ 1e7 leaves the f16 operand range of the expansion.  The
+    pack says so (read back by irbfn_net_set_params), the automatic choice stays on K1h, forcing K1g is refused."""
+    rng = np.random.default_rng(9)
+    D, K, O = 7, 128, 10
+    lo, hi = -5.0 * np.ones(D), 5.0 * np.ones(D)
+    cfg = _card(D, K, O, "gaussian", lo, hi)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(lo, hi, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": np.full((1, K), -7.0, np.float32)},
+                         "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": np.zeros(O, np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    x = rng.uniform(lo, hi, size=(500, D)).astype(np.float32)
+    auto = net.apply(params, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<"), net.last_launch()
+    with pytest.raises(ValueError, match="UNSUPPORTED"):
+        _run(net, params, x)
+    ref = orc.wcrbfnet_apply(cfg, orc.cast_params(params, np.float64), x.astype(np.float64))
+    assert np.abs(auto - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30) + 1e-12
+    # NaN parameters: refused as well (the statistics of the pack are not finite)
+    params["params"]["rbf_list"]["centers"][0, 3, 2] = np.nan
+    net2 = WCRBFNet.from_config(cfg)
+    net2.apply(params, x)
+    assert not net2.last_launch()["kernel"].startswith("rbf_fwd_f16gram")
+
+
+def test_gram_multi_region_nets_are_not_eligible(gpu):
+    cfg, params, x, *_ = load_ckpt_fixture("dnmpc_128regions")
+    net = WCRBFNet.from_config(cfg)
+    with pytest.raises(ValueError, match="UNSUPPORTED"):
+        _run(net, orc.cast_params(params, np.float32), x.astype(np.float32))

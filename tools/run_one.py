@@ -1,6 +1,6 @@
 """ONE kernel at ONE batch size, N launches: the unit of a per-(kernel, batch size) rocprofv3 summary
     rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/run_one.py <what> <B> [launches]
-what: fwd_cfg2 | fwd_cfg4_wide | tick_cfg4 | vjp_cfg3 | roll_<mode> | rollvjp_<mode> | spiral | spiralvjp | sparse_fwd |
+what: fwd_cfg2[_k1h|_k1g] | fwd_cfg4_wide | tick_cfg4 | vjp_cfg3 | roll_<mode> | rollvjp_<mode> | spiral | spiralvjp | sparse_fwd |
       sparse_tick | sparse_vjp | sparse_train      (mode: st_ks, st_select, fullint, frenet; T = 50, spiral N = 9)"""
 import json
 import os
@@ -41,8 +41,10 @@ def trained(run="dnmpc_128regions"):
     return WCRBFNet.from_config(cfg), P, x
 
 
-if what == "fwd_cfg2":
+if what in ("fwd_cfg2", "fwd_cfg2_k1h", "fwd_cfg2_k1g"):
     net, P = net_of(2); x = torch.from_numpy(configs.synth_queries(2, B=B)).cuda(); fn = lambda: net(x)
+    if what != "fwd_cfg2":
+        net.set_options(fwd_kernel=_lib.FWD_K1H if what.endswith("k1h") else _lib.FWD_K1G)
 elif what == "fwd_cfg4_wide":
     net, P = net_of(4); x = torch.from_numpy(configs.synth_queries(4, B=B)).cuda(); fn = lambda: net(x)
 elif what == "tick_cfg4":
