@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak == dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
-DTYPE = "f32 (Phi x W on f16 MFMA: hi/lo operand pairs, f32 accumulate)"
+DTYPE = "f32 (distances and Phi x W on f16 MFMA: exact fixed-point heads + float tails, hi/lo operand pairs; f32 accumulate)"
 
 
 def parse():
@@ -225,7 +225,8 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_fingerprint(names=("rbf_forward_f16.hip", "rbf_forward_f16_wide.h", "f16_split.h", "rbf_forward.h", "rbf_forward.hip")) -> str:
+def kernel_fingerprint(names=("rbf_forward_gram.hip", "rbf_forward_f16_narrow.h", "rbf_forward_f16.hip", "rbf_forward_f16_wide.h", "f16_split.h",
+                              "rbf_forward.h", "rbf_forward.hip")) -> str:
     """Hash of the sources the headline kernel is built from: profiles/*_traffic.json is only trusted for the
     code it was measured on (tools/measure_traffic.py stamps it)."""
     h = hashlib.sha1()
@@ -251,28 +252,49 @@ def forward_roofline(launch, B, N, D, O, kern_s):
             break
         elif rec:
             traffic_src = f"{tname} is stale (kernel sources or launch geometry changed since it was measured)"
-    # the kernel's work by execution unit: the Phi x W products run on the f16 matrix cores as 3 f16 products per
-    # f32 product (ph*wh, pl*wh, ph*wl), the outputs padded to one 16-wide tile; the rest is f32 VALU + 1 transcendental
-    valu_flops = B * N * (3 * D + 2)
-    mfma_flops = 2.0 * B * N * 16 * 3
-    return {
-        "bound": "mfma", "bound_detail": "compute roof; VALU-issue bound in fact (see note)", "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-        "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
-        "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
-        "note": "`bound` takes the contract's two values: 'mfma' here means the COMPUTE roof (as opposed to 'hbm'), priced as "
+    # the kernel's work by execution unit
+    gram = launch["kernel"].startswith("rbf_fwd_f16gram")
+    if gram:
+        # K1g: per 32 x 32 pairs 4 head MFMAs 16x16x16 + 8 tail MFMAs 16x16x32 (the squared distances as a Gram expansion:
+        # 10 + 42 of the 16 + 64 k-slots carry products) + 6 MFMAs 16x16x32 (Phi x W as 3 f16 products, O padded to 16);
+        # the VALU keeps one transcendental and the hi/lo split (3 instructions) per pair -- no algorithmic flops
+        valu_flops = 0.0
+        mfma_flops = B * N * (4 * 8192 + 14 * 16384) / 1024.0
+        detail = "compute roof; issue bound: the MFMA issue and the VALU issue of a SIMD add up (see note)"
+        note = ("`bound` takes the contract's two values: 'mfma' here means the COMPUTE roof (as opposed to 'hbm'), priced as "
+                "SURVEY 8d prescribes: algorithmic f32 flops (B*N*(3D+2+2O), transcendental count B*N) over the fp32 peak "
+                "157.3 TFLOP/s.  K1g evaluates BOTH GEMM-shaped pieces on the f16 matrix cores (the squared distances as an "
+                "exactly-cancelling Gram expansion, Phi x W as (hi, lo) pairs: 256 issued f16 flops per pair, 18 MFMAs per "
+                "32 x 32 pairs) and keeps one transcendental + a 3-instruction operand split per pair on the VALU; on a SIMD the "
+                "two issue streams add up (PMC: profiles/r03_gram_pmc.txt), so the kernel is bound by their sum, not by HBM "
+                "(2400 flop/B) and not by the matrix cores alone; `by_unit` prices the two pipes separately")
+        what_valu = "no algorithmic flops: B*N transcendentals and the hi/lo operand split (3 VALU instructions per pair)"
+        what_mfma = "issued f16 MFMA flops: distances (4 x 16x16x16 + 8 x 16x16x32 per 1024 pairs) + Phi x W (6 x 16x16x32)"
+    else:
+        # K1h: the Phi x W products run on the f16 matrix cores as 3 f16 products per f32 product (ph*wh, pl*wh, ph*wl), the
+        # outputs padded to one 16-wide tile; the rest is f32 VALU + 1 transcendental
+        valu_flops = B * N * (3 * D + 2)
+        mfma_flops = 2.0 * B * N * 16 * 3
+        detail = "compute roof; VALU-issue bound in fact (see note)"
+        note = ("`bound` takes the contract's two values: 'mfma' here means the COMPUTE roof (as opposed to 'hbm'), priced as "
                 "SURVEY 8d prescribes: algorithmic f32 flops (B*N*(3D+2+2O), transcendental count B*N) over the fp32 peak "
                 "157.3 TFLOP/s (fp32 vector == dense f32-input MFMA peak).  Within that roof the kernel is VALU/"
                 "transcendental-ISSUE bound (2400 flop/B, ~21.5 VALU instructions per pair; the matrix cores are ~7 % busy), "
-                "not MFMA-throughput bound and not HBM-bound; `by_unit` prices the two pipes it runs on separately",
+                "not MFMA-throughput bound and not HBM-bound; `by_unit` prices the two pipes it runs on separately")
+        what_valu = ("distances + basis argument (3D+2 per pair) on the f32 VALU; + B*N transcendentals and "
+                     "the hi/lo operand split (3.5 VALU instructions per pair, no algorithmic flops)")
+        what_mfma = "issued f16 MFMA flops: 3 products x 16-wide output tile (O = 10 padded) per pair"
+    return {
+        "bound": "mfma", "bound_detail": detail, "achieved": flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "frac": flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
+        "avg_launch_us": kern_s * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": abytes,
+        "note": note,
         "by_unit": {
             "valu_f32": {"flops": valu_flops, "tflops": valu_flops / kern_s / 1e12, "peak": PEAK_FP32_TFLOPS,
-                         "frac": valu_flops / kern_s / 1e12 / PEAK_FP32_TFLOPS,
-                         "what": "distances + basis argument (3D+2 per pair) on the f32 VALU; + B*N transcendentals and "
-                                 "the hi/lo operand split (3.5 VALU instructions per pair, no algorithmic flops)"},
+                         "frac": valu_flops / kern_s / 1e12 / PEAK_FP32_TFLOPS, "what": what_valu},
             "mfma_f16": {"flops": mfma_flops, "tflops": mfma_flops / kern_s / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
-                         "frac": mfma_flops / kern_s / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                         "what": "issued f16 MFMA flops: 3 products x 16-wide output tile (O = 10 padded) per pair"}},
+                         "frac": mfma_flops / kern_s / 1e12 / PEAK_F16_MFMA_TFLOPS, "what": what_mfma}},
         "hbm": {"achieved": abytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": abytes / kern_s / 1e9 / PEAK_HBM_GBS},
     }
@@ -428,6 +450,11 @@ def single_gpu_extras(net, params, x, configs, torch):
     out["cfg2_fp32_valu_K1"] = {"us": t * 1e6, "evals_per_s": B / t, "kernel": net.last_launch()["kernel"],
                                 "fp32_tflops": pairs2 * (3 * D + 2 + 2 * O) / t / 1e12,
                                 "frac_of_fp32_peak": pairs2 * (3 * D + 2 + 2 * O) / t / 1e12 / PEAK_FP32_TFLOPS}
+    # K1h: Phi x W on the matrix cores, the distances on the VALU (the headline kernel until K1g)
+    net.set_options(fwd_kernel=_lib.FWD_K1H)
+    t = _time(lambda: net(x), 50, torch)
+    out["cfg2_valu_distances_K1h"] = {"us": t * 1e6, "evals_per_s": B / t, "kernel": net.last_launch()["kernel"],
+                                      "frac_of_fp32_peak": pairs2 * (3 * D + 2 + 2 * O) / t / 1e12 / PEAK_FP32_TFLOPS}
     net.set_options(fwd_kernel=_lib.FWD_AUTO)
     g = torch.from_numpy(configs.synth_cotangent(3)).cuda()
     t = _time(lambda: (net(x), net.vjp(params, x, g)), 20, torch)
@@ -568,6 +595,7 @@ def single_gpu_extras(net, params, x, configs, torch):
     res5 = {"batch": B5, "centres": N5, "basis": card5["basis_func"]}
     ref_out = None
     for key, opts in (("fp32_valu_K1", {"fwd_kernel": _lib.FWD_K1}),
+                      ("f16_gram_K1g_fp32_accurate", {"fwd_kernel": _lib.FWD_K1G}),
                       ("f16x3_mfma_K1h_fp32_accurate", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 3}),
                       ("f16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 1}),
                       ("bf16_mfma_K1h_reduced_precision", {"fwd_kernel": _lib.FWD_K1H, "fwd_f16_terms": 2})):
@@ -582,6 +610,13 @@ def single_gpu_extras(net, params, x, configs, torch):
                  "algorithmic_fp32_tflops": pairs * (3 * 7 + 2 + 2 * 10) / t / 1e12,
                  "valu_f32_frac": pairs * 23 / t / 1e12 / PEAK_FP32_TFLOPS,
                  "max_rel_dev_vs_fp32_kernel": float(np.abs(o5 - ref_out).max() / np.abs(ref_out).max())}
+        if "K1g" in key:
+            entry["valu_f32_frac"] = 0.0                     # distances on the matrix cores: no algorithmic flops left on the VALU
+            entry["mfma_f16"] = {"tflops": pairs * 256 / t / 1e12, "frac": pairs * 256 / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                 "busy_frac": pairs / 1024 * 18 * 16.0 / (t * 2.4e9 * 1024),
+                                 "what": "matrix-core utilisation asked for by BASELINE config 5: issued f16 MFMA flops (distances "
+                                         "as a Gram expansion + Phi x W: 18 MFMAs of 16 cycles per 32 x 32 pairs) over the dense "
+                                         "f16 peak, and MFMA cycles over SIMD time at 2.4 GHz"}
         if "K1h" in key:
             terms = 3 if "x3" in key else 1
             entry["mfma_f16"] = {"tflops": pairs * 2 * 16 * terms / t / 1e12,

@@ -324,17 +324,20 @@ bool f16_narrow_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_ou
 // expansion (gram_ok, set by the pack)
 bool gram_preferred(const irbfn_net* net, int64_t B) {
   const int ot = net->opt[IRBFN_OPT_FWD_F16_TERMS];
-  return net->gram_img && net->gram_ok && net->O <= 16 && (ot == 3 || ot == 0) && B >= opt_or(net, IRBFN_OPT_FWD_F16_MINB, 65);
+  // below ~12k queries K1h's eight centre slices per query group finish sooner (config-2 net: B = 8192 27 vs 35 us,
+  // B = 16384 44 vs 37 us)
+  return net->gram_img && net->gram_ok && net->O <= 16 && (ot == 3 || ot == 0) && B >= 12288;
 }
 
-// S centre slices x QG query groups: the QG waves of a slice share one stream of chunk images, so QG is as large as the
-// batch allows while the launch still has ~4 waves per SIMD
+// S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (21 KiB of LDS per
+// slice).  Measured at the config-2 net (us; B = 16384 / 32768 / 65536 / 262144): S = 4, QG = 2: 36 / 71 / 135 / 529;
+// S = 2, QG = 4: 52 / 54 / 83 / 297; S = 1, QG = 8: 90 / 90 / 91 / 275 -- more slices while the launch is short of waves, never
+// more blocks than are resident at once.
 void gram_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_out) {
   const long groups = (B + 31) / 32;
   const int nchunks = (net->N + 31) / 32;
-  // measured at config 2 (B = 65536, N = 4096): S = 2, QG = 4 85 us; S = 1, QG = 4 88; S = 1, QG = 8 96; S = 2, QG = 8 93
-  int S = 1;
-  while (S < 4 && groups * S < 4096 && nchunks / (2 * S) >= 4) S *= 2;     // a slice's ring is 21 KiB of LDS
+  int S = groups <= 768 ? 4 : (groups <= 3072 ? 2 : 1);
+  while (S > 1 && nchunks / (2 * S) < 4) S /= 2;            // at least 8 chunks per wave
   S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
   if (S > 7 || S > nchunks) S = 1;
   int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);

@@ -42,7 +42,7 @@ def _card(D, K, O, basis, lo, hi, delta=20.0):
 def test_gram_is_the_default_at_config_2_and_as_accurate_as_the_float32_kernel(gpu):
     cfg, params = configs.model_card(2), configs.synth_params(2)
     net = WCRBFNet.from_config(cfg)
-    B = 4096 + 37                                    # ragged tail
+    B = 4 * 4096 + 37                                # ragged tail; the automatic choice takes K1g from 12288 queries
     x = configs.synth_queries(2, B=B)
     auto = net.apply(params, x)
     assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<D=7,BC=0"), net.last_launch()
@@ -147,11 +147,13 @@ def test_gram_ill_conditioned_columns(gpu, case, basis):
     params = {"params": {"rbf_list": {"centers": centers, "log_sigs": log_sigs},
                          "linear": {"kernel": W.astype(np.float32), "bias": np.zeros(O, np.float32)}}}
     net = WCRBFNet.from_config(cfg)
-    got = net.apply(params, x)
-    name = net.last_launch()["kernel"]
-    if case == "outlier_far_centre":                        # the gaussian's 2 alpha c' leaves the budget, the algebraic bases' do not
-        assert name.startswith("rbf_fwd_f16mfma<" if basis == "gaussian" else "rbf_fwd_f16gram<"), name
+    if case == "outlier_far_centre" and basis == "gaussian":     # 2 alpha c' leaves the budget: refused, the net stays on K1h
+        with pytest.raises(ValueError, match="UNSUPPORTED"):
+            _run(net, params, x)
+        got, name = _run(net, params, x, kernel=_lib.FWD_AUTO)
+        assert name.startswith("rbf_fwd_f16mfma<"), name
     else:
+        got, name = _run(net, params, x)
         assert name.startswith("rbf_fwd_f16gram<"), name
     k1, _ = _run(net, params, x, kernel=_lib.FWD_K1)
     ref = orc.wcrbfnet_apply(cfg, orc.cast_params(params, np.float64), x.astype(np.float64))
@@ -234,6 +236,7 @@ def test_gram_refuses_parameters_outside_its_budget(gpu):
                          "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": np.zeros(O, np.float32)}}}
     net = WCRBFNet.from_config(cfg)
     x = rng.uniform(lo, hi, size=(500, D)).astype(np.float32)
+    x = np.tile(x, (30, 1))                               # 15000 queries: the automatic choice would take K1g
     auto = net.apply(params, x)
     assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<"), net.last_launch()
     with pytest.raises(ValueError, match="UNSUPPORTED"):
