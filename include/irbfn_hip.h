@@ -93,8 +93,12 @@ int irbfn_net_destroy(irbfn_net* net);
 
 /* Binds the parameter pytree {"rbf_list": {"centers"[R,K,D], "log_sigs"[R,K]},
  * "linear": {"kernel"[K,O], "bias"[O]}} (checkpoint layout).  Device pointers; the
- * data is re-packed on `stream` into the descriptor's own record buffer (one tiny kernel), so the
- * caller may overwrite its arrays afterwards.  Call again after every optimiser step. */
+ * data is re-packed on `stream` into the descriptor's own record buffers (a few small kernels), so the
+ * caller may overwrite its arrays afterwards.  Call again after every optimiser step.  For nets the
+ * matrix-core kernel K1g can take (one region, O <= 16, d <= 7, fast basis) the call ends with ONE small
+ * synchronous read-back on `stream` (64 bytes: do the bound parameters fit K1g's expansion?) -- the
+ * kernel choice of later forwards is a property of the parameters; every other net returns without
+ * synchronising. */
 int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* log_sigs_dev,
                          const float* kernel_dev, const float* bias_dev, void* stream);
 
@@ -123,12 +127,15 @@ typedef enum irbfn_option {
   IRBFN_OPT_COUNT = 14
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
-  IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; one region + fast basis + O <= 128: K1h; O > 16: K1m; otherwise K1 */
+  IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; sparse multi-region gate: K1r; one region + fast basis: K1g (O <= 16, B >= 12288, parameters
+                         inside its budget) else K1h (O <= 128); O > 16: K1m; otherwise K1 */
   IRBFN_FWD_K1 = 1,   /* rbf_fwd_qlane: all-float32 VALU kernel (any net) */
   IRBFN_FWD_K1M = 2,  /* rbf_fwd_mfma: Phi x W on the f32-input matrix cores */
   IRBFN_FWD_K1H = 3,  /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
   IRBFN_FWD_K1R = 4,  /* rbf_fwd_sparse: several regions, every query visits only the regions whose gamma != 0 */
-  IRBFN_FWD_K1G = 5   /* rbf_fwd_f16gram: one region, O <= 16: distances as a Gram expansion on the f16 matrix cores as well */
+  IRBFN_FWD_K1G = 5   /* rbf_fwd_f16gram: one region, O <= 16, d <= 7: the squared distances as an exactly-cancelling Gram expansion
+                         on the f16 matrix cores in front of K1h's Phi x W; IRBFN_ERR_UNSUPPORTED when the bound parameters
+                         do not fit the expansion (widths of 1e-3 of the centres' spread, non-finite values) */
 } irbfn_fwd_kernel;
 typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3 } irbfn_vjp_kernel;
 /* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
