@@ -39,6 +39,7 @@ UNITS = [
     # float64 mode (--use_float64 of the reference): plain f64 VALU kernels
     ("rbf_f64.hip", "rbf_f64.o", []),
     ("rbf_forward_gram.hip", "rbf_forward_gram.o", []),
+    ("rbf_forward_gram_wide.hip", "rbf_forward_gram_wide.o", []),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
     ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace

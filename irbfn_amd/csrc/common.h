@@ -122,6 +122,7 @@ int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs,
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s);
 bool gram_eligible(const irbfn_net* net);
 bool gram_preferred(const irbfn_net* net, int64_t B);
+bool gram_wide_preferred(const irbfn_net* net, int64_t B);
 void gram_geometry(const irbfn_net* net, int64_t B, int* S, int* QG);
 size_t gram_image_bytes(const irbfn_net* net);
 size_t gram_header_bytes();

@@ -329,6 +329,11 @@ bool gram_preferred(const irbfn_net* net, int64_t B) {
   return net->gram_img && net->gram_ok && net->O <= 16 && (ot == 3 || ot == 0) && B >= 12288;
 }
 
+// K1g for wide outputs (rbf_forward_gram_wide.hip): d = 7, the parameters fit the expansion
+bool gram_wide_preferred(const irbfn_net* net, int64_t B) {
+  return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && net->DC == 7 && B >= 2048;
+}
+
 // S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (21 KiB of LDS per
 // slice).  Measured at the config-2 net (us; B = 16384 / 32768 / 65536 / 262144): S = 4, QG = 2: 36 / 71 / 135 / 529;
 // S = 2, QG = 4: 52 / 54 / 83 / 297; S = 1, QG = 8: 90 / 90 / 91 / 275 -- more slices while the launch is short of waves, never
@@ -354,6 +359,10 @@ static int try_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B
   if (net->O > 16) {
     int SW, QGw;
     if (!f16_wide_geometry(net, B, &SW, &QGw)) return IRBFN_ERR_UNSUPPORTED;
+    if (e == IRBFN_FWD_AUTO && gram_wide_preferred(net, B)) {  // K1g's wide form: the distances on the matrix cores as well
+      const int rc = launch_forward_gram(net, x, out, B, 1, 1, s);
+      if (rc != IRBFN_ERR_UNSUPPORTED) return rc;
+    }
     return launch_forward_f16(net, x, out, B, SW, QGw, 3, s);
   }
   int S, QG;
@@ -385,7 +394,7 @@ int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStr
   // a kernel that is "not eligible" answers IRBFN_ERR_UNSUPPORTED; every other status (a HIP launch failure
   // of the preferred kernel in particular) is returned, never papered over by the next kernel in line
   if (forced == IRBFN_FWD_K1G) {
-    if (!net->gram_img || !net->gram_ok || net->O > 16) return IRBFN_ERR_UNSUPPORTED;
+    if (!net->gram_img || !net->gram_ok) return IRBFN_ERR_UNSUPPORTED;
     int Sg, QGg;
     gram_geometry(net, B, &Sg, &QGg);
     return launch_forward_gram(net, x, out, B, Sg, QGg, s);

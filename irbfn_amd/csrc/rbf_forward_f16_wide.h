@@ -94,6 +94,108 @@ struct F16Roll {                        // the roll-out behind the forward (fuse
   DynParams dp;
 };
 
+// The epilogue of the pipelined wide kernels (K1h rbf_fwd_f16mfma_wide_pipe / rbf_tick_f16mfma_wide, K1g's wide form): gate of the
+// single region (model.py:42-95), the SW centre slices summed per column tile in fixed order through LDS, scale, bias, store;
+// MODE >= 0: the block's controls stay in LDS and its slice-0 waves roll the trajectories out (rollout_pair.h).  acc / acl: A1 / A2
+// of f16_split.h per query tile and column tile; inv_scale: 1 / (scale of the basis values x 2^15).  Every wave of the block
+// arrives here; the ring is dead.
+template <int DC, int NT, int MODE>
+__device__ __forceinline__ void wide_epilogue(const F16Args& a, const F16Roll& rl, unsigned char* lds, const f4_t (&acc)[2][NT],
+                                              const f4_t (&acl)[2][NT], int slice, int qg, long q0, float inv_scale) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, n = lane & 15;
+  const int SW = a.S, QG = a.QG;
+  long qrow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long q = q0 + t * 16 + n;
+    q = q < a.B ? q : a.B - 1;
+    qrow[t] = q < 0 ? 0 : q;
+  }
+  const GateTables gt = a.gate;
+  float gam[2] = {0.0f, 0.0f};
+  if (slice == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;
+#pragma unroll
+      for (int d = 0; d < DC; ++d)
+        if (d < gt.nsplit && gt.n_ranges > 0) {
+          const int e = d * gt.max_ranges + gt.dim_ranges[d];
+          gv *= gate_factor(a.x[qrow[t] * a.Dreal + d], gt.lo[e], gt.hi[e], gt.delta[d]);
+        }
+      gam[t] = gv;
+    }
+  }
+  __syncthreads();                                           // every wave is done with the ring
+  float* red = reinterpret_cast<float*>(lds);                // [SW][QG][2][4][64]
+  float* gl = red + (size_t)SW * QG * 2 * 4 * 64;            // [QG][32]
+  [[maybe_unused]] float* ctile = gl + QG * 32;              // MODE >= 0: the block's controls [QG * 32][CP]
+  [[maybe_unused]] const int CP = a.O | 1;                   // odd pitch: a lane's row reads spread over the banks
+  if (slice == 0 && g == 0) { gl[qg * 32 + n] = gam[0]; gl[qg * 32 + 16 + n] = gam[1]; }
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(((slice * QG + qg) * 2 + t) * 4 + r) * 64 + lane] = __builtin_fmaf(acl[t][ct][r], kLoScale, acc[t][ct][r]);
+    __syncthreads();
+    const int o = ct * 16 + n;
+    if (slice == 0 && o < a.O) {
+      const float sc = a.oscale[o] * inv_scale;
+      const float bi = a.bias[o];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.0f;
+          for (int s2 = 0; s2 < SW; ++s2) v += red[(((s2 * QG + qg) * 2 + t) * 4 + r) * 64 + lane];
+          const int row = t * 16 + 4 * g + r;
+          const long q = q0 + row;
+          float y = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);
+          if constexpr (MODE >= 0) {
+            // planner mirror trick (irbfn_planner.py:203-204): steering-rate knots of mirrored rows change sign
+            if (rl.mirror != nullptr && o >= rl.T && q < a.B && rl.mirror[q] != 0) y = -y;
+            ctile[(qg * 32 + row) * CP + o] = y;             // rows past the batch hold the clamped last query: finite, unused
+          }
+          if (q < a.B && a.out != nullptr) a.out[q * a.O + o] = y;
+        }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (MODE >= 0) {
+    // ---- the roll-out of the block's QG x 32 trajectories (K3p core, rollout_pair.h) by its slice-0 waves: the controls
+    // never leave the CU between the two stages.  Each lane pulls ONE control stream of its row into registers; after
+    // the barrier the tile is dead and the LDS becomes the waves' output staging tiles.
+    static_assert(MODE == IRBFN_ROLLOUT_ST_SELECT || MODE == IRBFN_ROLLOUT_ST_KS, "instantiated for the single-track tick");
+    constexpr int S = ModeTraits<MODE>::S;
+    constexpr int TS = pair_ts(S);
+    const int T = rl.T;
+    const int odd = lane & 1, prow = lane >> 1;
+    const long left = a.B - q0;
+    const int nvalid = left < kPairRows ? (left > 0 ? (int)left : 0) : kPairRows;
+    const bool roller = slice == 0 && nvalid > 0;
+    float st[S], ctl[kTickTch];
+#pragma unroll
+    for (int t = 0; t < kTickTch; ++t) ctl[t] = 0.0f;
+    if (roller) {
+      const long bb = q0 + (prow < nvalid ? prow : nvalid - 1);
+#pragma unroll
+      for (int i = 0; i < S; ++i) st[i] = rl.state0[bb * S + i];
+      const float* ur = ctile + (qg * 32 + prow) * CP + (odd ? T : 0);
+#pragma unroll
+      for (int t = 0; t < kTickTch; ++t)
+        if (t < T) ctl[t] = ur[t];
+    }
+    __syncthreads();                                         // the controls tile is dead
+    if (!roller) return;
+    float* tile = reinterpret_cast<float*>(lds) + (size_t)qg * rl.wlds;
+    pair_rollout_run<MODE, kTickTch, TS>(st, ctl, rl.dp, tile, rl.states + q0 * (long)T * S, T, nvalid, lane);
+  }
+}
+
 // MODE < 0: forward only.  MODE >= 0 (plan_tick_wide.hip): the block's controls stay in LDS and its slice-0 waves roll
 // the trajectories out (rollout_pair.h) -- the planning tick in ONE launch.
 template <int DC, int BC, int NT, int MODE>
@@ -244,88 +346,7 @@ __device__ __forceinline__ void wide_pipe_body(const F16Args& a, const F16Roll& 
   }
   if (na > 0) body(BoolC<false>{}, BoolC<true>{}, ring, ring + bprv * CB);      // the products of the slice's last chunk
 
-  const GateTables gt = a.gate;
-  float gam[2] = {0.0f, 0.0f};
-  if (slice == 0) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float gv = gt.n_ranges > 0 ? 1.0f : 0.0f;
-#pragma unroll
-      for (int d = 0; d < DC; ++d)
-        if (d < gt.nsplit && gt.n_ranges > 0) {
-          const int e = d * gt.max_ranges + gt.dim_ranges[d];
-          gv *= gate_factor(xq[t][d], gt.lo[e], gt.hi[e], gt.delta[d]);
-        }
-      gam[t] = gv;
-    }
-  }
-  __syncthreads();                                           // every wave is done with the ring
-  float* red = reinterpret_cast<float*>(lds);                // [SW][QG][2][4][64]
-  float* gl = red + (size_t)SW * QG * 2 * 4 * 64;            // [QG][32]
-  [[maybe_unused]] float* ctile = gl + QG * 32;              // MODE >= 0: the block's controls [QG * 32][CP]
-  [[maybe_unused]] const int CP = a.O | 1;                   // odd pitch: a lane's row reads spread over the banks
-  if (slice == 0 && g == 0) { gl[qg * 32 + n] = gam[0]; gl[qg * 32 + 16 + n] = gam[1]; }
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        red[(((slice * QG + qg) * 2 + t) * 4 + r) * 64 + lane] = __builtin_fmaf(acl[t][ct][r], kLoScale, acc[t][ct][r]);
-    __syncthreads();
-    const int o = ct * 16 + n;
-    if (slice == 0 && o < a.O) {
-      const float sc = a.oscale[o] * (1.0f / (16384.0f * kWScale));
-      const float bi = a.bias[o];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = 0.0f;
-          for (int s2 = 0; s2 < SW; ++s2) v += red[(((s2 * QG + qg) * 2 + t) * 4 + r) * 64 + lane];
-          const int row = t * 16 + 4 * g + r;
-          const long q = q0 + row;
-          float y = __builtin_fmaf(gl[qg * 32 + row] * v, sc, bi);
-          if constexpr (MODE >= 0) {
-            // planner mirror trick (irbfn_planner.py:203-204): steering-rate knots of mirrored rows change sign
-            if (rl.mirror != nullptr && o >= rl.T && q < a.B && rl.mirror[q] != 0) y = -y;
-            ctile[(qg * 32 + row) * CP + o] = y;             // rows past the batch hold the clamped last query: finite, unused
-          }
-          if (q < a.B && a.out != nullptr) a.out[q * a.O + o] = y;
-        }
-    }
-    __syncthreads();
-  }
-
-  if constexpr (MODE >= 0) {
-    // ---- the roll-out of the block's QG x 32 trajectories (K3p core, rollout_pair.h) by its slice-0 waves: the controls
-    // never leave the CU between the two stages.  Each lane pulls ONE control stream of its row into registers; after
-    // the barrier the tile is dead and the LDS becomes the waves' output staging tiles.
-    static_assert(MODE == IRBFN_ROLLOUT_ST_SELECT || MODE == IRBFN_ROLLOUT_ST_KS, "instantiated for the single-track tick");
-    constexpr int S = ModeTraits<MODE>::S;
-    constexpr int TS = pair_ts(S);
-    const int T = rl.T;
-    const int odd = lane & 1, prow = lane >> 1;
-    const long left = a.B - q0;
-    const int nvalid = left < kPairRows ? (left > 0 ? (int)left : 0) : kPairRows;
-    const bool roller = slice == 0 && nvalid > 0;
-    float st[S], ctl[kTickTch];
-#pragma unroll
-    for (int t = 0; t < kTickTch; ++t) ctl[t] = 0.0f;
-    if (roller) {
-      const long bb = q0 + (prow < nvalid ? prow : nvalid - 1);
-#pragma unroll
-      for (int i = 0; i < S; ++i) st[i] = rl.state0[bb * S + i];
-      const float* ur = ctile + (qg * 32 + prow) * CP + (odd ? T : 0);
-#pragma unroll
-      for (int t = 0; t < kTickTch; ++t)
-        if (t < T) ctl[t] = ur[t];
-    }
-    __syncthreads();                                         // the controls tile is dead
-    if (!roller) return;
-    float* tile = reinterpret_cast<float*>(lds) + (size_t)qg * rl.wlds;
-    pair_rollout_run<MODE, kTickTch, TS>(st, ctl, rl.dp, tile, rl.states + q0 * (long)T * S, T, nvalid, lane);
-  }
+  wide_epilogue<DC, NT, MODE>(a, rl, lds, acc, acl, slice, qg, q0, 1.0f / (16384.0f * kWScale));
 }
 
 

@@ -35,45 +35,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "rbf_forward_f16_narrow.h"
+#include "rbf_forward_gram.h"
 
 namespace irbfn {
-
-typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-
-constexpr int kGramHeadBytes = 2 * 64 * 8;                       // [ct][lane] 4 halfs
-constexpr int kGramTailBytes = 2 * 2 * 64 * 16;                  // [ct][half][lane] 8 halfs
-constexpr int kGramChunkBytes = kGramHeadBytes + kGramTailBytes + 2 * kF16WBytes;   // 7 KiB
-constexpr int kGramDims = 7;
-#ifndef IRBFN_GRAM_WAVES
-#define IRBFN_GRAM_WAVES 4     // waves per SIMD the register allocation must allow
-#endif
-
-struct GramHdr {
-  float r[8];                 // origin (midpoint of the centres' box)
-  int ex, ec, eq, ea, e2;     // |x'_i| < 2^ex, |C| < 2^ec, Q < 2^eq, |alpha| < 2^ea, |c2| < 2^e2
-  int ok;
-  float cabs, amax, cmax, c2max;
-};
-
-// ---- the slot tables: which product sits in which k-slot ---------------------------------------------------------
-struct GramSlot { int kind, dim, p, q; };        // kind: 0 empty, 1 x'_dim part p x C part q, 2 Q part p x alpha part q, 3 1 x c2 part p
-__host__ __device__ constexpr GramSlot gram_head_slot(int s) {
-  return s < kGramDims ? GramSlot{1, s, 0, 0}
-                       : (s == 7 ? GramSlot{2, 0, 0, 0} : (s == 8 ? GramSlot{3, 0, 0, 0} : (s == 9 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})));
-}
-__host__ __device__ constexpr int gram_comb_p(int m) { return m == 0 ? 0 : (m == 1 ? 1 : (m == 2 ? 0 : (m == 3 ? 2 : 1))); }
-__host__ __device__ constexpr int gram_comb_q(int m) { return m == 0 ? 1 : (m == 1 ? 0 : (m == 2 ? 2 : (m == 3 ? 0 : 1))); }
-__host__ __device__ constexpr GramSlot gram_tail_slot(int s) {
-  return s < 5 * kGramDims ? GramSlot{1, s / 5, gram_comb_p(s % 5), gram_comb_q(s % 5)}
-                           : (s < 5 * kGramDims + 5 ? GramSlot{2, 0, gram_comb_p(s - 5 * kGramDims), gram_comb_q(s - 5 * kGramDims)}
-                                                    : (s < 5 * kGramDims + 7 ? GramSlot{3, 0, s - 5 * kGramDims - 5 + 2, 0} : GramSlot{0, 0, 0, 0}));
-}
-// power-of-two weight of a slot's product and its split between the two operands (both kept near 2^(T/2))
-__host__ __device__ inline int gram_T(const GramHdr& h, const GramSlot sl) {
-  return sl.kind == 1 ? h.ex + h.ec - 11 * (sl.p + sl.q) : (sl.kind == 2 ? h.eq + h.ea - 11 * (sl.p + sl.q) : h.e2 - 11 * sl.p);
-}
-__host__ __device__ inline int gram_ax(int T) { return (T + 1) >> 1; }      // query-side exponent; centre side: T - ax
 
 // ---- pack ------------------------------------------------------------------------------------------------
 template <int BC>
@@ -82,12 +46,6 @@ __device__ inline void gram_alpha_beta(double s2, double gscale, double& alpha, 
   else if (BC == BC_IQ) { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                // P = 1 / (2^-14 (1 + d2 s2))
   else { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                                 // P = rsqrt(2^-14 (1 + d2 s2)) = 2^7 phi
 }
-// The inverse multiquadric arrives as P = 2^7 phi here (K1h: 2^14 phi, argument 2^-28 (1 + t)): an argument scaled by 2^-28
-// would push the tail operands of the expansion -- 2^-11 and 2^-22 of the heads -- below the f16 normal range.  2^7 phi is a
-// normal f16 number down to phi = 2^-21, which an algebraically decaying basis does not reach.
-template <int BC>
-__host__ __device__ constexpr float gram_phi_scale() { return BC == BC_IMQ ? 128.0f : kPhiScale; }
-
 __device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e
   if (!(v > 0.0)) return -40;
   int e;
@@ -206,14 +164,14 @@ template <int BC>
 __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                         const float* __restrict__ kernel, const float* __restrict__ oscale,
                                                         const GramHdr* __restrict__ hdr, unsigned char* __restrict__ img, int N,
-                                                        int K, int D, int O, float gscale, int nchunks) {
+                                                        int K, int D, int O, int NT, float gscale, int nchunks) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nchunks * kF16Chunk) return;
   const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
   const int n = idx;
   const bool real = n < N;
   const GramHdr h = *hdr;
-  unsigned char* p = img + (size_t)c * kGramChunkBytes;
+  unsigned char* p = img + (size_t)c * gram_chunk_bytes(NT);
   const int ct = kk >> 4, row = kk & 15;                     // centre tile, A-operand row
   double nC[kGramDims][3], nA[3], n2[4];
   for (int i = 0; i < kGramDims; ++i) nC[i][0] = nC[i][1] = nC[i][2] = 0.0;
@@ -252,87 +210,26 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
   }
   // W rows in the k order of the Phi x W product: centre 16 ct + 4 g + r <-> k = 8 g + 4 ct + r
   const int g = row >> 2, j = ct * 4 + (row & 3);
-  _Float16* wh = reinterpret_cast<_Float16*>(p + kGramHeadBytes + kGramTailBytes);
-  _Float16* wl = wh + kF16WBytes / 2;
-  for (int oo = 0; oo < 16; ++oo) {
-    float w = 0.0f;
-    if (real && oo < O) w = kernel[(size_t)(n % K) * O + oo] / oscale[oo];
-    _Float16 hh, ll;
-    split_static_f16(w, hh, ll);
-    wh[(g * 16 + oo) * 8 + j] = hh;
-    wl[(g * 16 + oo) * 8 + j] = ll;
+  for (int wt = 0; wt < NT; ++wt) {                          // column tiles of 16 outputs: W hi, W lo
+    _Float16* wh = reinterpret_cast<_Float16*>(p + kGramOpBytes + (size_t)wt * 2 * kF16WBytes);
+    _Float16* wl = wh + kF16WBytes / 2;
+    for (int oo = 0; oo < 16; ++oo) {
+      const int o = wt * 16 + oo;
+      float w = 0.0f;
+      if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
+      _Float16 hh, ll;
+      split_static_f16(w, hh, ll);
+      wh[(g * 16 + oo) * 8 + j] = hh;
+      wl[(g * 16 + oo) * 8 + j] = ll;
+    }
   }
 }
 
-// Diagnosis build only (tools/build_variant.py ... -DIRBFN_GRAM_STAMPS): wave 0 of blocks 0 and 1 add up s_memtime per
-// phase of the step; no output depends on it and the regular build contains none of it.
-#ifdef IRBFN_GRAM_STAMPS
-__device__ unsigned long long g_gram_stamps[32];
-#define IRBFN_GRAM_T() __builtin_amdgcn_s_memtime()
-#else
-#define IRBFN_GRAM_T() 0ull
-#endif
-
 // ---- kernel ----------------------------------------------------------------------------------------------
-typedef float f2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-
-// The (hi, lo) pair of f16_split.h in three instructions per value instead of four: hi = the packed round-toward-zero
-// conversion itself (the leading 11 bits of P wherever P is a normal f16 number), lo = 2^11 (P - hi) as one v_fma_mix_f32
-// that reads hi as the f16 number it is: fma(hi, -2^11, 2^11 P) is exact (every term a multiple of the last bit of P).
-// (v_pk_add_f32 / v_pk_mul_f32 for the subtraction and the gain: measured slower -- packed f32 VALU costs more than the two
-// plain instructions it replaces, MI355X_MICROARCH.md constants table.)
-__device__ __forceinline__ void split_pair_mix(float p0, float p1, unsigned& hi, unsigned& lo) {
-  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-  const float q0 = p0 * kLoGain, q1 = p1 * kLoGain;
-  float d0, d1;
-  const float ng = -kLoGain;
-  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "s"(ng), "v"(q0));
-  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "s"(ng), "v"(q1));
-  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
-}
-
-// the step's 16 transcendentals back to back (rbf_forward.h, trans_block), from the MFMA result registers into fresh ones
-template <int BC>
-__device__ __forceinline__ void trans16(const f4_t (&u)[2][2], float (&o)[16]) {
-#define IRBFN_T8(OP, T)                                                                                                          \
-  asm volatile(OP " %0, %8\n " OP " %1, %9\n " OP " %2, %10\n " OP " %3, %11\n " OP " %4, %12\n " OP " %5, %13\n " OP " %6, %14\n " OP     \
-               " %7, %15" IRBFN_T8_TAIL##T                                                                                       \
-               : "=&v"(o[8 * T]), "=&v"(o[8 * T + 1]), "=&v"(o[8 * T + 2]), "=&v"(o[8 * T + 3]), "=&v"(o[8 * T + 4]),           \
-                 "=&v"(o[8 * T + 5]), "=&v"(o[8 * T + 6]), "=&v"(o[8 * T + 7])                                                   \
-               : "v"(u[T][0][0]), "v"(u[T][0][1]), "v"(u[T][0][2]), "v"(u[T][0][3]), "v"(u[T][1][0]), "v"(u[T][1][1]),           \
-                 "v"(u[T][1][2]), "v"(u[T][1][3]));
-#define IRBFN_T8_TAIL0 ""
-#define IRBFN_T8_TAIL1 "\n s_nop 7"
-  if constexpr (BC == BC_GAUSS) { IRBFN_T8("v_exp_f32_e32", 0) IRBFN_T8("v_exp_f32_e32", 1) }
-  else if constexpr (BC == BC_IQ) { IRBFN_T8("v_rcp_f32_e32", 0) IRBFN_T8("v_rcp_f32_e32", 1) }
-  else { IRBFN_T8("v_rsq_f32_e32", 0) IRBFN_T8("v_rsq_f32_e32", 1) }
-#undef IRBFN_T8
-#undef IRBFN_T8_TAIL0
-#undef IRBFN_T8_TAIL1
-}
-
-struct GramArgs {
-  F16Args f;                              // x, img = K1h's image (records of the VALU path), oscale, bias, out, gate, B, ...
-  const unsigned char* __restrict__ gimg; // [nchunks][kGramChunkBytes]
-  const GramHdr* __restrict__ hdr;
-};
-
-// |v| < 2^E given as vh + vl -> normalised parts (float), as gram_parts_d
-__device__ __forceinline__ void gram_parts_f(float vh, float vl, float inv, float (&n)[3]) {
-  const float a = vh * inv, b = vl * inv;                    // exact (power of two)
-  n[0] = __builtin_rintf(a * 1024.0f) * (1.0f / 1024.0f);
-  const float r1 = ((a - n[0]) + b) * 2048.0f;               // a - n0 is exact
-  n[1] = (float)(_Float16)r1;
-  const float r2 = (r1 - n[1]) * 2048.0f;
-  n[2] = (float)(_Float16)r2;
-}
-
 template <int DC, int BC, bool ROLL>
 __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl, int mode, unsigned char* lds) {
   static_assert(DC <= kGramDims, "seven coordinate slots");
   const F16Args& a = ga.f;
-  constexpr int RF = f16_rf(DC);
   constexpr int CBL = f16_chunk_bytes(DC);                   // K1h's chunk image (the VALU path reads its records)
   constexpr int CB = kGramChunkBytes;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -342,9 +239,6 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
   const int g = lane >> 4, n = lane & 15;
   const long q0 = ((long)blockIdx.x * QG + qg) * 32;
   const GramHdr* hp = ga.hdr;
-  const int ex = hp->ex, ec = hp->ec, eq = hp->eq, ea = hp->ea, e2 = hp->e2;
-  GramHdr hx;                                                // exponents only (gram_T)
-  hx.ex = ex; hx.ec = ec; hx.eq = eq; hx.ea = ea; hx.e2 = e2;
   long qrow[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -355,57 +249,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
   // ---- query-side operands: B[k = slot][column = query]
   h4_t bhd[2];
   h8_t btl[2][2];
-  bool bad = hp->ok == 0;
-  {
-    const float xinv = __builtin_ldexpf(1.0f, -ex), qinv = __builtin_ldexpf(1.0f, -eq);
-    const float xlim = __builtin_ldexpf(1.0f, ex) * 0.999f, qlim = __builtin_ldexpf(1.0f, eq) * 0.999f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float nx[kGramDims][3], nq[3];
-      float qh = 0.0f, ql = 0.0f;
-#pragma unroll
-      for (int i = 0; i < kGramDims; ++i) {
-        if (i < DC) {
-          const float xv = i < a.Dreal ? a.x[qrow[t] * a.Dreal + i] : 0.0f;
-          const float rr = -hp->r[i];
-          const float sh = xv + rr;                          // TwoSum: x' = sh + sl exactly
-          const float bb = sh - xv;
-          const float sl = (xv - (sh - bb)) + (rr - bb);
-          bad = bad || !(__builtin_fabsf(sh) < xlim);        // NaN / Inf / outside the box
-          gram_parts_f(sh, sl, xinv, nx[i]);
-          const float ph = sh * sh;                          // Q += x'^2 in double-float
-          const float pl = __builtin_fmaf(sh, sh, -ph) + 2.0f * sh * sl;
-          const float th = qh + ph;
-          const float tb = th - qh;
-          ql += ((qh - (th - tb)) + (ph - tb)) + pl;
-          qh = th;
-        } else {
-          nx[i][0] = nx[i][1] = nx[i][2] = 0.0f;
-        }
-      }
-      bad = bad || !(qh < qlim);
-      gram_parts_f(qh, ql, qinv, nq);
-      auto xval = [&](const GramSlot sl) -> float {
-        if (sl.kind == 0) return 0.0f;
-        const float sc = __builtin_ldexpf(1.0f, gram_ax(gram_T(hx, sl)));
-        return sl.kind == 1 ? nx[sl.dim][sl.p] * sc : (sl.kind == 2 ? nq[sl.p] * sc : sc);
-      };
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v0 = xval(gram_head_slot(j)), v1 = xval(gram_head_slot(4 + j)), v2 = xval(gram_head_slot(8 + j)),
-                    v3 = xval(gram_head_slot(12 + j));
-        bhd[t][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
-      }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v0 = xval(gram_tail_slot(32 * hf + j)), v1 = xval(gram_tail_slot(32 * hf + 8 + j)),
-                      v2 = xval(gram_tail_slot(32 * hf + 16 + j)), v3 = xval(gram_tail_slot(32 * hf + 24 + j));
-          btl[t][hf][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
-        }
-    }
-  }
+  const bool bad = gram_query_operands<DC>(a, hp, qrow, g, bhd, btl);
   const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;     // wave-uniform: the VALU distances for these 32 queries
 
   const int c0 = (int)((long)a.nchunks * slice / S), c1 = (int)((long)a.nchunks * (slice + 1) / S);
@@ -431,33 +275,11 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
 
   f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A1: ph * wh
   f4_t acl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A2: pls * wh + ph * wls
-  // the argument of the transcendental for the 2 x 2 tiles of chunk `buf`: head sum (exact), then the tails
-  auto distances = [&](const unsigned char* buf, f4_t (&u)[2][2]) {
-    h4_t ahd[2];
-    h8_t atl[2][2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      ahd[ct] = *reinterpret_cast<const h4_t*>(buf + ct * 512 + lane * 8);
-      atl[ct][0] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 0) * 1024 + lane * 16);
-      atl[ct][1] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 1) * 1024 + lane * 16);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-        u[t][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahd[ct], bhd[t], f4_t{0, 0, 0, 0}, 0, 0, 0);   // exact head sum
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          u[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(atl[ct][hf], btl[t][hf], u[t][ct], 0, 0, 0);
-  };
+  auto distances = [&](const unsigned char* buf, f4_t (&u)[2][2]) { gram_distances(buf, lane, bhd, btl, u); };
   // transcendental, hi / lo split and Phi x W of the 16 pairs in t16 with the W operands of chunk `buf`
   auto products = [&](float (&t16)[16], const unsigned char* buf, auto pre) {
-    const h8_t bh = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + kGramTailBytes + lane * 16);
-    const h8_t bl = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + kGramTailBytes + kF16WBytes + lane * 16);
+    const h8_t bh = *reinterpret_cast<const h8_t*>(buf + kGramOpBytes + lane * 16);
+    const h8_t bl = *reinterpret_cast<const h8_t*>(buf + kGramOpBytes + kF16WBytes + lane * 16);
     pre(t16);                                                // P = 2^kPhiExp * phi for the step's 16 pairs
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -515,26 +337,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
     for (int i = 0; i < nsteps; ++i) {
       if (i < na) {
         float t16[16];
-        const float* recs = reinterpret_cast<const float*>(a.img + (size_t)(c0 + i) * CBL);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          float xq[DC];
-#pragma unroll
-          for (int d = 0; d < DC; ++d) xq[d] = d < a.Dreal ? a.x[qrow[t] * a.Dreal + d] : 0.0f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float* rp = recs + ((j >> 2) * 16 + 4 * g + (j & 3)) * RF;
-            float r2 = 0.0f;
-#pragma unroll
-            for (int d = 0; d < DC; ++d) {
-              const float df = xq[d] - rp[d];                // flax_rbf.py:280
-              r2 = __builtin_fmaf(df, df, r2);
-            }
-              float arg = f16_arg<BC>(r2, rp[RF - 1]);
-            if constexpr (BC == BC_IMQ) arg *= kPhiScale;    // 2^7 phi here (gram_phi_scale), K1h's records are scaled for 2^14 phi
-            t16[t * 8 + j] = arg;
-          }
-        }
+        gram_valu_args<DC, BC>(a, qrow, g, reinterpret_cast<const float*>(a.img + (size_t)(c0 + i) * CBL), t16);
         products(t16, ring + b0 * CB, [&](float (&o)[16]) { trans_block<BC, 16>(o); });
       }
       step_barrier();
@@ -580,13 +383,15 @@ __global__ __launch_bounds__(1024, IRBFN_GRAM_WAVES) void rbf_tick_f16gram(const
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
+static int gram_nt(const irbfn_net* net) { return (net->O + 15) / 16; }
+
 bool gram_eligible(const irbfn_net* net) {
-  return f16_eligible(net) && net->O <= 16 && net->DC <= kGramDims;
+  return f16_eligible(net) && net->DC <= kGramDims;
 }
 
 size_t gram_image_bytes(const irbfn_net* net) {
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
-  return (size_t)nchunks * kGramChunkBytes;
+  return (size_t)nchunks * gram_chunk_bytes(gram_nt(net));
 }
 
 size_t gram_header_bytes() { return sizeof(GramHdr); }
@@ -603,9 +408,9 @@ int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs
   const dim3 grid((total + 255) / 256), block(256);
   const float gs = gauss_scale(net->basis);
   switch (net->bclass) {
-    case BC_GAUSS: hipLaunchKernelGGL((gram_pack_kernel<BC_GAUSS>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
-    case BC_IQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
-    case BC_IMQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IMQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gs, nchunks); break;
+    case BC_GAUSS: hipLaunchKernelGGL((gram_pack_kernel<BC_GAUSS>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
+    case BC_IQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
+    case BC_IMQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IMQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
@@ -650,6 +455,7 @@ static int launch_gram_bc(const GramArgs& a, int bc, int grid, int block, size_t
 // S centre slices x QG query groups of 32 per block (S * QG <= 8 waves)
 int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, hipStream_t s) {
   if (!net->gram_img || !net->f16_img || !gram_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
+  if (net->O > 16) return launch_forward_gram_wide(net, x, out, B, S, QG, s);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   if (S < 1 || QG < 1 || S * QG > 16 || S > nchunks) return IRBFN_ERR_BAD_ARG;
   GramArgs a;

@@ -100,15 +100,15 @@ def test_cfg4_share_forward_and_tick(gpu):
     net = WCRBFNet.from_config(cfg)
     xt, st = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda()
     ctrl, states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
-    assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide")                  # ONE launch: forward + roll-out
+    assert net.last_launch()["kernel"].startswith(("rbf_tick_f16gram_wide", "rbf_tick_f16mfma_wide"))                  # ONE launch: forward + roll-out
     u = net.apply(P, xt)
-    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma_wide")
+    assert net.last_launch()["kernel"].startswith(("rbf_fwd_f16gram_wide", "rbf_fwd_f16mfma_wide"))
     assert torch.equal(ctrl, u)
     two = dyn.integrate_st_ks_mult(torch.cat([st, u], dim=1), configs.DYN_PARAMS)
     assert torch.equal(states, two)                                                         # fused == two launches
     net.set_options(tick_fused=0)
     ctrl2, states2 = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
-    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma_wide")
+    assert net.last_launch()["kernel"].startswith(("rbf_fwd_f16gram_wide", "rbf_fwd_f16mfma_wide"))
     net.set_options(tick_fused=1)
     assert torch.equal(ctrl2, ctrl) and torch.equal(states2, states)
     sub = np.arange(0, B, 8)                                                                # 4096 rows
@@ -189,7 +189,7 @@ def test_cfg4_fused_tick_mirror_and_ragged(gpu, B):
     for mode, fn in ((_lib.ROLLOUT_ST_KS, dyn.integrate_st_ks_mult), (_lib.ROLLOUT_ST_SELECT, dyn.integrate_st_mult)):
         ctrl, states = plan_tick(net, P, xt, mt, st, configs.DYN_PARAMS, mode=mode)
         # small batches run 4 centre slices per block (the pipelined kernel's LDS ring does not fit): separate launches
-        assert net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide" if B > 8192 else "rollout_fwd") or B <= 8192
+        assert net.last_launch()["kernel"].startswith(("rbf_tick_f16gram_wide", "rbf_tick_f16mfma_wide") if B > 8192 else "rollout_fwd") or B <= 8192
         u = net.apply(P, xt).clone()
         u[:, T:] = torch.where(mt[:, None] != 0, -u[:, T:], u[:, T:])
         assert torch.equal(ctrl, u)
@@ -216,7 +216,7 @@ def test_cfg4_fused_tick_other_instances(gpu, basis, T):
     net = WCRBFNet.from_config(cfg)
     xt, st = torch.from_numpy(x).cuda(), torch.from_numpy(st0).cuda()
     ctrl, states = plan_batch(net, P, xt, st, configs.DYN_PARAMS, mode=_lib.ROLLOUT_ST_KS)
-    fused = net.last_launch()["kernel"].startswith("rbf_tick_f16mfma_wide")
+    fused = net.last_launch()["kernel"].startswith(("rbf_tick_f16gram_wide", "rbf_tick_f16mfma_wide"))
     assert fused == (T <= 50)
     u = net.apply(P, xt)
     assert torch.equal(ctrl, u)

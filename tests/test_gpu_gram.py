@@ -255,3 +255,81 @@ def test_gram_multi_region_nets_are_not_eligible(gpu):
     net = WCRBFNet.from_config(cfg)
     with pytest.raises(ValueError, match="UNSUPPORTED"):
         _run(net, orc.cast_params(params, np.float32), x.astype(np.float32))
+
+
+# ---- wide outputs (16 < O <= 128): rbf_fwd_f16gram_wide, rbf_forward_gram_wide.h ------------------------------------------
+@pytest.mark.parametrize("O,SW,basis", [(100, 2, "gaussian"), (100, 1, "gaussian"), (20, 4, "inverse_quadratic"), (64, 1, "inverse_multiquadric"),
+                                        (128, 2, "gaussian"), (33, 0, "gaussian")])
+def test_gram_wide_outputs(gpu, O, SW, basis):
+    """50-step control sequences (O = 100) and the other column-tile counts: K1g's wide form against float64, the f32 matrix-core
+    kernel K1m and K1h's wide kernel."""
+    rng = np.random.default_rng(O + SW)
+    D, K = 7, 300
+    cfg = dict(configs.model_card(4), num_kernels=K, out_features=O, basis_func=basis)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(-1, 8, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": rng.uniform(0.0, 2.0, size=(1, K)).astype(np.float32)},
+                         "linear": {"kernel": rng.normal(0, 0.3, size=(K, O)).astype(np.float32),
+                                    "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    for B in (777, 2500):
+        x = configs.synth_queries(4, B=B)
+        got, name = _run(net, params, x, fwd_f16_s=SW)
+        assert name.startswith("rbf_fwd_f16gram_wide<") and (SW == 0 or f"SW={min(SW, 2 if O > 48 else 4)}" in name), name
+        p64 = orc.cast_params(params, np.float64)
+        ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+        scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+        assert got.shape == (B, O)
+        other, nm = _run(net, params, x, kernel=_lib.FWD_K1M)
+        assert nm.startswith("rbf_fwd_mfma")
+        err, err_other = (np.abs(got - ref) / scale).max(), (np.abs(other - ref) / scale).max()
+        assert err <= max(2e-6, 2.0 * err_other), (err, err_other)
+        assert (np.abs(got - other) / scale).max() <= 1e-5
+        auto = net.apply(params, x)                           # the automatic choice takes it from 2048 queries
+        assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram_wide<" if B >= 2048 else "rbf_fwd_f16mfma_wide"), net.last_launch()
+        assert (np.abs(auto - ref) / scale).max() <= max(3e-6, 2.0 * err_other)
+
+
+@pytest.mark.parametrize("O,case", [(100, "six_decades"), (40, "six_decades"), (100, "on_centres")])
+def test_gram_wide_ill_conditioned_columns(gpu, O, case):
+    from test_gpu_f16 import _cond_net
+    K = 300
+    rng, cfg, centers, log_sigs = _cond_net(K, O, "gaussian", seed=O)
+    B = 1024 + 3
+    x = rng.uniform(0.0, 4.0, size=(B, 7)).astype(np.float32)
+    W = 10.0 ** rng.uniform(-3, 3, size=(K, O))
+    if case == "on_centres":
+        x[:512] = centers[0, rng.integers(0, K, size=512)]
+    params = {"params": {"rbf_list": {"centers": centers, "log_sigs": log_sigs},
+                         "linear": {"kernel": W.astype(np.float32), "bias": np.zeros(O, np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    got, name = _run(net, params, x)
+    assert name.startswith("rbf_fwd_f16gram_wide<"), name
+    ref = orc.wcrbfnet_apply(cfg, orc.cast_params(params, np.float64), x.astype(np.float64))
+    rel = np.abs(got - ref) / ref
+    print(f"wide {case}/O={O}: max rel {rel.max():.2e}")
+    assert rel.max() <= 1e-5, (case, O, rel.max())
+
+
+def test_gram_wide_queries_outside_the_box(gpu):
+    cfg, params = configs.model_card(4), configs.synth_params(4)
+    net = WCRBFNet.from_config(cfg)
+    B = 32 * 70 + 9
+    x = configs.synth_queries(4, B=B)
+    clean, _ = _run(net, params, x)
+    xb = x.copy()
+    xb[5, 1] = 4.0e2
+    xb[77, 0] = np.inf
+    xb[200, 6] = np.nan
+    got, name = _run(net, params, xb)
+    assert name.startswith("rbf_fwd_f16gram_wide<")
+    k1h, _ = _run(net, params, xb, kernel=_lib.FWD_K1H)
+    rows_bad = np.concatenate([np.arange(g * 32, (g + 1) * 32) for g in sorted({5 // 32, 77 // 32, 200 // 32})])
+    rows_ok = np.setdiff1d(np.arange(B), rows_bad)
+    assert np.array_equal(got[rows_ok], clean[rows_ok])
+    fin = rows_bad[np.isfinite(xb[rows_bad]).all(axis=1)]
+    p64 = orc.cast_params(params, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, xb[fin].astype(np.float64))
+    scale = _terms_scale(cfg, p64, xb[fin].astype(np.float64)) + 1e-30
+    assert (np.abs(got[fin] - ref) / scale).max() <= 3e-6 and (np.abs(got[fin] - k1h[fin]) / scale).max() <= 3e-6
+    assert np.isnan(got[200]).all() and np.isfinite(got[[5, 77]]).all()
+    assert np.allclose(got[77], np.asarray(params["params"]["linear"]["bias"], np.float32), atol=1e-6)
