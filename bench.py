@@ -507,12 +507,22 @@ def single_gpu_extras(net, params, x, configs, torch):
     x4 = torch.from_numpy(configs.synth_queries(4, B=32768)).cuda()
     t = _time(lambda: net4(x4), 20, torch)
     pairs4 = 32768.0 * 4096
+    kern4 = net4.last_launch()["kernel"]
+    gram4 = kern4.startswith("rbf_fwd_f16gram_wide")
+    # issued f16 MFMA flops per pair: Phi x W 3 products x 7 column tiles of 16 (O = 100 padded to 112); K1g adds the distances
+    # (4 x 16x16x16 + 8 x 16x16x32 per 32 x 32 pairs = 160 per pair) and takes the 3D + 2 distance flops off the VALU
+    mf4 = pairs4 * (2 * 112 * 3 + (160 if gram4 else 0))
     out["cfg4_forward_O100_per_gpu_share"] = {
-        "us": t * 1e6, "evals_per_s": 32768 / t, "kernel": net4.last_launch()["kernel"],
-        "valu_f32": {"tflops": pairs4 * 23 / t / 1e12, "frac": pairs4 * 23 / t / 1e12 / PEAK_FP32_TFLOPS},
-        "mfma_f16": {"tflops": pairs4 * 2 * 112 * 3 / t / 1e12, "frac": pairs4 * 2 * 112 * 3 / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                     "what": "issued f16 MFMA flops: 3 products x 7 column tiles of 16 (O = 100 padded to 112)"},
+        "us": t * 1e6, "evals_per_s": 32768 / t, "kernel": kern4,
+        "valu_f32": {"tflops": (0.0 if gram4 else pairs4 * 23 / t / 1e12), "frac": (0.0 if gram4 else pairs4 * 23 / t / 1e12 / PEAK_FP32_TFLOPS)},
+        "mfma_f16": {"tflops": mf4 / t / 1e12, "frac": mf4 / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                     "what": "issued f16 MFMA flops: 3 products x 7 column tiles of 16 (O = 100 padded to 112)"
+                             + (" + the squared distances as a Gram expansion (K1g)" if gram4 else "")},
         "algorithmic_fp32_tflops": pairs4 * (3 * 7 + 2 + 200) / t / 1e12}
+    net4.set_options(fwd_kernel=_lib.FWD_K1H)
+    t_h = _time(lambda: net4(x4), 20, torch)
+    out["cfg4_forward_O100_per_gpu_share"]["K1h_wide_us"] = t_h * 1e6
+    net4.set_options(fwd_kernel=_lib.FWD_AUTO)
     # the planning tick at the per-GPU share: forward + 50-step roll-out in ONE launch (controls stay in LDS) against
     # forward -> roll-out as separate launches through a controls buffer, and the forward alone (interleaved repeats)
     s4 = torch.from_numpy(configs.initial_state_from_query(x4.cpu().numpy())).cuda()

@@ -48,7 +48,10 @@ void gram_wide_geometry(const irbfn_net* net, int64_t B, int* SW_out, int* QG_ou
   if (net->opt[IRBFN_OPT_FWD_F16_S] > 0) SW = net->opt[IRBFN_OPT_FWD_F16_S];
   if (SW != 1 && SW != 2 && SW != 4) SW = 1;
   while (SW > 1 && ((size_t)SW * 3 * gram_chunk_bytes(NT) > 160 * 1024 || nchunks / SW < 2)) SW /= 2;
-  int QG = net->opt[IRBFN_OPT_FWD_F16_QG] > 0 ? net->opt[IRBFN_OPT_FWD_F16_QG] : 8 / SW;
+  // query groups per block, measured at config 4 (us; B = 8192 / 32768 / 262144): SW=2 QG=2: 88 / 173 / 1359; SW=2 QG=4: 109 / 117 / 863;
+  // SW=1 QG=4: 133 / 136 / 698; SW=1 QG=8: 183 / 186 / 742 (K1h's wide kernel: 102 / 132 / 921)
+  int QG = groups <= 384 ? 2 : (SW == 1 ? 4 : 8 / SW);
+  if (net->opt[IRBFN_OPT_FWD_F16_QG] > 0) QG = net->opt[IRBFN_OPT_FWD_F16_QG];
   if (QG < 1 || SW * QG > 8) QG = 8 / SW;
   *SW_out = SW; *QG_out = QG;
 }
