@@ -137,7 +137,7 @@ typedef enum irbfn_fwd_kernel {
                          on the f16 matrix cores in front of K1h's Phi x W; IRBFN_ERR_UNSUPPORTED when the bound parameters
                          do not fit the expansion (widths of 1e-3 of the centres' spread, non-finite values) */
 } irbfn_fwd_kernel;
-typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3 } irbfn_vjp_kernel;
+typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3, IRBFN_VJP_K2G = 4 } irbfn_vjp_kernel;
 /* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
 int irbfn_net_set_option(irbfn_net* net, int option, int value);
 int irbfn_net_get_option(const irbfn_net* net, int option, int* value_out);

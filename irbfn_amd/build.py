@@ -41,7 +41,8 @@ UNITS = [
     ("rbf_forward_gram.hip", "rbf_forward_gram.o", []),
     ("rbf_forward_gram_wide.hip", "rbf_forward_gram_wide.o", []),
     ("rbf_vjp.hip", "rbf_vjp.o", [] + _SLP),
-    ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
+    ("rbf_vjp_f16.hip", "rbf_vjp_f16.o", ["-fno-slp-vectorize"]),
+    ("rbf_vjp_gram.hip", "rbf_vjp_gram.o", ["-fno-slp-vectorize"]),   # VGPR operands: plain FMAs (2.4 cyc) beat packed (4.7) + pairing moves
     # 12-step unrolled groups of the roll-out; no SLP: v_pk_* cost more than the two plain VALU instructions they replace
     ("rollout.hip", "rollout.o", ["-mllvm", "-pragma-unroll-threshold=100000", "-fno-slp-vectorize"]),
     # the fused planning tick: wide K1h forward + K3p roll-out core in one kernel (the roll-out's flags: 50-knot register arrays)

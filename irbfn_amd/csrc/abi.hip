@@ -149,7 +149,7 @@ int irbfn_net_set_option(irbfn_net* net, int option, int value) {
   if (!net || option < 0 || option >= IRBFN_OPT_COUNT || value < 0) return IRBFN_ERR_BAD_ARG;
   switch (option) {
     case IRBFN_OPT_FWD_KERNEL: if (value > IRBFN_FWD_K1G) return IRBFN_ERR_BAD_ARG; break;
-    case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2R) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_VJP_KERNEL: if (value > IRBFN_VJP_K2G) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_SMALL: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_F16_TERMS: if (value != 1 && value != 2 && value != 3) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_FWD_Q: if (value > 2) return IRBFN_ERR_BAD_ARG; break;

@@ -359,6 +359,7 @@ struct VjpPlan {
   size_t off_gamma, off_part, off_bias, off_qrec, off_qblk, off_misc, total;
   int QS;
   bool use_h;      // K2h (matrix-core VJP) instead of K2
+  bool use_g;      // K2g (u and the centre gradients on the matrix cores too) in front of K2h
   int CT;
   bool use_sp;     // K2r (region-sparse VJP, rbf_sparse.hip) instead of K2
   int SL;          // K2r: slices per region (<= QSB slabs are allocated)
@@ -394,7 +395,9 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   const int vk = net->opt[IRBFN_OPT_VJP_KERNEL];
   p.use_h = vjph_eligible(net) && vk != IRBFN_VJP_K2 && B >= 2048;
   p.CT = net->opt[IRBFN_OPT_VJP_F16_CT] == 4 ? 4 : 2;
-  p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * vjph_block_bytes(net) : 0);
+  const size_t blkb = vjph_block_bytes(net) > vjpg_block_bytes() ? vjph_block_bytes(net) : vjpg_block_bytes();
+  p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * blkb : 0);
+  p.use_g = p.use_h && vjpg_eligible(net) && (vk == IRBFN_VJP_K2G || (vk == IRBFN_VJP_AUTO && B >= 16384)) && net->opt[IRBFN_OPT_VJP_F16_CT] == 0;
   p.off_misc = off;  off += al((size_t)(p.bias_blocks + 8) * sizeof(float));
   // K2r: several regions with a sparse gate (automatic where the forward takes K1r; IRBFN_VJP_K2R forces it where eligible)
   p.use_sp = sparse_vjp_eligible(net) && (vk == IRBFN_VJP_K2R || (vk == IRBFN_VJP_AUTO && sparse_preferred(net, B)));
@@ -407,7 +410,15 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
     p.off_sp_part = off;                          // K2r's own slabs [SL][V][Npad]
     off += al((size_t)p.SL * p.V * p.Npad * sizeof(float));
   }
-  if (p.use_h) {
+  if (p.use_g) {
+    // K2g: a block = 4 waves = 128 centres; slices so that the launch has ~4096 waves, at least 8 query blocks each
+    const long nqb = (B + 31) / 32;
+    const long gb = ((net->N + 31) / 32 + 3) / 4;
+    long q2 = (1024 + gb - 1) / gb;
+    if (q2 * 8 > nqb) q2 = (nqb + 7) / 8;
+    if (q2 < 1) q2 = 1;
+    if (q2 < p.QSB) p.QSB = (int)q2;          // never more slabs than were allocated above
+  } else if (p.use_h) {
     // fewer, longer query slices than K2 (3 waves per SIMD resident): halves the slab traffic of the reduce kernel
     const long gh = (net->N + 16 * p.CT - 1) / (16 * p.CT);
     long q2 = (6144 + gh * 4 - 1) / (gh * 4);
@@ -713,6 +724,7 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   }
   VjpPlan p = make_plan(net, B);
   if (gamma_ext) p.use_h = false;                // caller-provided region weights (ClusterWCRBFNet): the gated K2
+  if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2G && !(p.use_h && p.use_g)) return IRBFN_ERR_UNSUPPORTED;   // a forced kernel that cannot take the net
   char* base = static_cast<char*>(ws);
   float* gamma = reinterpret_cast<float*>(base + p.off_gamma);
   float* part = reinterpret_cast<float*>(base + p.off_part);
@@ -724,8 +736,21 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
                        (long)B, net->O, p.rows_per_block, bmax);
     IRBFN_HIP_CHECK(hipGetLastError());
-    int rch = launch_vjp_f16(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks,
-                             scales, part, p.QSB, p.Npad, p.CT, s);
+    int rch;
+    const int* run_if = nullptr;
+    if (p.use_g) {
+      // K2g first; a query outside its representable box raises the flag, K2g returns at once and K2h -- launched behind it
+      // with the complementary test -- does the work
+      int* flag = reinterpret_cast<int*>(scales + 4);
+      rch = launch_vjp_gram(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks, scales, flag,
+                            part, p.QSB, p.Npad, s);
+      if (rch != IRBFN_OK) return rch;
+      run_if = flag;
+    } else if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2G) {
+      return IRBFN_ERR_UNSUPPORTED;
+    }
+    rch = launch_vjp_f16(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks,
+                         scales, part, p.QSB, p.Npad, p.CT, s, run_if);
     if (rch != IRBFN_OK) return rch;
     rch = launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s);
     if (rch != IRBFN_OK) return rch;

@@ -333,3 +333,97 @@ def test_gram_wide_queries_outside_the_box(gpu):
     assert (np.abs(got[fin] - ref) / scale).max() <= 3e-6 and (np.abs(got[fin] - k1h[fin]) / scale).max() <= 3e-6
     assert np.isnan(got[200]).all() and np.isfinite(got[[5, 77]]).all()
     assert np.allclose(got[77], np.asarray(params["params"]["linear"]["bias"], np.float32), atol=1e-6)
+
+
+# ---- K2g: the parameter VJP with u and the centre gradients on the matrix cores as well (rbf_vjp_gram.hip) -----------------
+LEAVES = (("rbf_list", "centers"), ("rbf_list", "log_sigs"), ("linear", "kernel"), ("linear", "bias"))
+
+
+def _vjp_case(case, rng):
+    if case == "cfg3":
+        cfg = dict(configs.model_card(3), num_kernels=500)                 # not a multiple of 32 / 128: idle waves in the last block
+        P = configs.synth_params(3)
+        P = {"params": {"rbf_list": {k: v[:, :500] for k, v in P["params"]["rbf_list"].items()},
+                        "linear": {"kernel": P["params"]["linear"]["kernel"][:500], "bias": P["params"]["linear"]["bias"]}}}
+        B = 4096 + 19
+        x, g = configs.synth_queries(3, B=B), configs.synth_cotangent(3, B=B) * 1e-3
+    elif case == "iq_ckpt":
+        cfg, P, *_ = load_ckpt_fixture("dnmpc_1regions_newnewdata_1stepst_l1_newarch_ksint_iq")
+        P = orc.cast_params(P, np.float32)
+        ns = len(cfg["activation_idx"])
+        lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+        B = 3000
+        x = rng.uniform(lo - 0.02, hi + 0.02, size=(B, 7)).astype(np.float32)
+        g = rng.normal(size=(B, 2)).astype(np.float32) * 40.0
+    elif case == "gauss_ckpt":
+        cfg, P, *_ = load_ckpt_fixture("dnmpc_1regions_newdata_oldintloss_nomirror_highk")
+        P = orc.cast_params(P, np.float32)
+        ns = len(cfg["activation_idx"])
+        lo = np.array([min(cfg["lower_bounds"][d]) for d in range(ns)]); hi = np.array([max(cfg["upper_bounds"][d]) for d in range(ns)])
+        B = 2500
+        x = rng.uniform(lo - 0.02, hi + 0.02, size=(B, 7)).astype(np.float32)
+        g = rng.normal(size=(B, 10)).astype(np.float32)
+    else:
+        D, K, O = 3, 96, 5
+        cfg = _card(D, K, O, "inverse_multiquadric", [-2.0] * D, [3.0] * D)
+        P = {"params": {"rbf_list": {"centers": rng.uniform(-3, 4, size=(1, K, D)).astype(np.float32),
+                                     "log_sigs": rng.uniform(-0.5, 1.0, size=(1, K)).astype(np.float32)},
+                        "linear": {"kernel": (rng.normal(size=(K, O)) * np.array([1e-2, 1, 1, 50, 1])).astype(np.float32),
+                                   "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+        B = 2048 + 1
+        x = rng.uniform(-2.2, 3.2, size=(B, D)).astype(np.float32)
+        g = rng.normal(size=(B, O)).astype(np.float32)
+        g[7] = 0.0
+    return cfg, P, x, g
+
+
+@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "gauss_ckpt", "imq_d3"])
+def test_vjp_gram_matches_valu_kernel_and_oracle(gpu, case):
+    import torch
+    cfg, P, x, g = _vjp_case(case, np.random.default_rng(11))
+    net = WCRBFNet.from_config(cfg)
+    xt, gt = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    net.set_options(vjp_kernel=_lib.VJP_K2G)
+    a = net.vjp(P, xt, gt)["params"]
+    a2 = net.vjp(P, xt, gt)["params"]
+    net.set_options(vjp_kernel=_lib.VJP_K2)
+    b = net.vjp(P, xt, gt)["params"]
+    net.set_options(vjp_kernel=_lib.VJP_AUTO)
+    ref = orc.wcrbfnet_vjp(cfg, orc.cast_params(P, np.float64), x.astype(np.float64), g.astype(np.float64))["params"]
+    for grp, name in LEAVES:
+        ga, gb, gr = a[grp][name].cpu().numpy(), b[grp][name].cpu().numpy(), np.asarray(ref[grp][name])
+        assert torch.equal(a[grp][name], a2[grp][name])                    # deterministic
+        scale = np.abs(gr).max() + 1e-30
+        ea, eb = np.abs(ga - gr).max() / scale, np.abs(gb - gr).max() / scale
+        print(f"{case} {name}: K2g {ea:.2e}  K2 {eb:.2e}")
+        assert ea <= max(2e-5, 2.0 * eb), (case, grp, name, ea, eb)
+
+
+def test_vjp_gram_hands_over_when_a_query_leaves_the_box(gpu):
+    """A query outside the representable box of the expansion raises the pre-pass's flag: K2g returns at once and K2h, launched
+    behind it, computes the slabs -- the gradients are right either way (here against the float64 restatement)."""
+    import torch
+    cfg, P, x, g = _vjp_case("cfg3", np.random.default_rng(3))
+    x = x.copy()
+    x[100, 2] = 300.0                                      # far outside: gamma = 0, contributes nothing, cannot be expanded
+    x[2000, 0] = -1.0e4
+    net = WCRBFNet.from_config(cfg)
+    xt, gt = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    net.set_options(vjp_kernel=_lib.VJP_K2G)
+    a = net.vjp(P, xt, gt)["params"]
+    net.set_options(vjp_kernel=_lib.VJP_AUTO)
+    ref = orc.wcrbfnet_vjp(cfg, orc.cast_params(P, np.float64), x.astype(np.float64), g.astype(np.float64))["params"]
+    for grp, name in LEAVES:
+        gr = np.asarray(ref[grp][name])
+        assert np.abs(a[grp][name].cpu().numpy() - gr).max() <= 2e-5 * (np.abs(gr).max() + 1e-30), (grp, name)
+
+
+def test_vjp_gram_is_refused_where_the_expansion_is(gpu):
+    import torch
+    cfg, P, x, *_ = load_ckpt_fixture("dnmpc_128regions")
+    net = WCRBFNet.from_config(cfg)
+    net.set_options(vjp_kernel=_lib.VJP_K2G)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    with pytest.raises(ValueError, match="UNSUPPORTED"):
+        net.vjp(orc.cast_params(P, np.float32), xt, torch.ones(x.shape[0], cfg["out_features"], device="cuda"))
+    net.set_options(vjp_kernel=_lib.VJP_AUTO)
