@@ -302,6 +302,9 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
     // two steps per trip: the distances of chunk i + 1 are issued in front of the VALU work on chunk i
     f4_t ua[2][2], ub[2][2];
     if (na > 0) distances(ring, ua);
+    // trans16 is inline asm: the hazard recogniser does not see it read MFMA results.  In the loop the 12 distance MFMAs of the
+    // next chunk lie in front of it; a slice of ONE chunk reads them right away: explicit wait states, once
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     int b0 = 0;                                              // ring slot of chunk i
     [[maybe_unused]] unsigned long long tph[5] = {0, 0, 0, 0, 0};
     auto one_step = [&](int i, f4_t (&ucur)[2][2], f4_t (&unxt)[2][2]) {

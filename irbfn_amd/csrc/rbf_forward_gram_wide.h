@@ -104,6 +104,9 @@ __device__ __forceinline__ void wide_gram_body(const GramArgs& ga, const F16Roll
     // arguments of chunk i are consumed: one set of 16 argument registers -- and the Phi x W MFMAs of chunk i behind them
     f4_t u[2][2];
     if (na > 0) gram_distances(ring, lane, bhd, btl, u);
+    // trans16 is inline asm: the hazard recogniser does not see it read MFMA results.  In the loop 6 NT MFMAs lie between the
+    // distance MFMAs and the transcendentals that read them; here, once, explicit wait states do
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     int b0 = 0;                                              // ring slot of chunk i
     for (int i = 0; i < nsteps; ++i) {
       const int b1 = next3(b0);

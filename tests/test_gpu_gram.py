@@ -97,7 +97,7 @@ def test_gram_on_the_reference_s_trained_single_region_planner(gpu, B):
 
 @pytest.mark.parametrize("D,K,O,basis", [(3, 256, 5, "gaussian"), (4, 96, 16, "inverse_multiquadric"), (7, 200, 2, "inverse_quadratic"),
                                          (7, 33, 1, "gaussian_wide"), (5, 64, 7, "inverse_multiquadric"), (2, 50, 3, "gaussian_wider"),
-                                         (6, 1000, 10, "gaussian")])
+                                         (6, 1000, 10, "gaussian"), (7, 20, 4, "gaussian"), (4, 32, 16, "inverse_quadratic")])
 def test_gram_shapes_and_bases(gpu, D, K, O, basis):
     rng = np.random.default_rng(D * 100 + K)
     lo, hi = -np.ones(D) * 2, np.ones(D) * 3
