@@ -124,7 +124,11 @@ typedef enum irbfn_option {
   IRBFN_OPT_TICK_FUSED = 13,   /* planning tick on the matrix-core kernels: 1 (default) one launch where the instance exists (wide: d = 7,
                                   O = 2T in (96, 112], single-track modes; narrow: O = 2T <= 16, d = 7 single-track / inline bicycle,
                                   d = 8 Frenet), 0: forward + sign flip + roll-out launches */
-  IRBFN_OPT_COUNT = 14
+  IRBFN_OPT_GRAM_STICKY = 14,  /* K1g / K2g: 0 (default) every irbfn_net_set_params reads the pack's verdict back (one small synchronous copy);
+                                  1: only the first one does and later calls keep its verdict -- for training loops, which re-bind every step.
+                                  The kernels test the device-side verdict themselves and fall back to the VALU distances / to K2h, so a stale
+                                  host verdict costs speed, never correctness */
+  IRBFN_OPT_COUNT = 15
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
   IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; sparse multi-region gate: K1r; one region + fast basis: K1g (d <= 7, parameters inside its budget; O <= 16:
@@ -138,7 +142,9 @@ typedef enum irbfn_fwd_kernel {
                          do not fit the expansion (widths of 1e-3 of the centres' spread, non-finite values) */
 } irbfn_fwd_kernel;
 typedef enum irbfn_vjp_kernel { IRBFN_VJP_AUTO = 0, IRBFN_VJP_K2 = 1, IRBFN_VJP_K2H = 2, IRBFN_VJP_K2R = 3, IRBFN_VJP_K2G = 4 } irbfn_vjp_kernel;
-/* A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
+/* K2: all-float32 VALU; K2H: hbar and dW on the f16 matrix cores; K2R: region-sparse pair lists; K2G: the squared distances (K1g's
+ * expansion) and the centre gradients on the matrix cores as well -- automatic from 16384 queries where K1g's expansion fits.
+ * A forced kernel that cannot take the net answers IRBFN_ERR_UNSUPPORTED at the call that would launch it. */
 int irbfn_net_set_option(irbfn_net* net, int option, int value);
 int irbfn_net_get_option(const irbfn_net* net, int option, int* value_out);
 

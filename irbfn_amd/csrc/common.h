@@ -80,6 +80,7 @@ struct irbfn_net {
   void* gram_hdr;           // K1g: origin and exponents of the expansion (device, written by the pack)
   int gram_ok;              // K1g: the parameters fit the expansion's exactness budget (read back by set_params)
   int gram_exp[5];          // K1g: exponents ex, ec, eq, ea, e2 (diagnostics)
+  int gram_checked;         // K1g: gram_ok has been read back at least once (IRBFN_OPT_GRAM_STICKY)
   float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
   unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs

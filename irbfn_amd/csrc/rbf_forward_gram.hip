@@ -46,6 +46,9 @@ __device__ inline void gram_alpha_beta(double s2, double gscale, double& alpha, 
   else if (BC == BC_IQ) { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                // P = 1 / (2^-14 (1 + d2 s2))
   else { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                                 // P = rsqrt(2^-14 (1 + d2 s2)) = 2^7 phi
 }
+__device__ inline double gram_pow2(int e) {                  // 2^e, -1022 <= e <= 1023, without the library's ldexp
+  return __builtin_bit_cast(double, (unsigned long long)(1023 + e) << 52);
+}
 __device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e
   if (!(v > 0.0)) return -40;
   int e;
@@ -57,36 +60,46 @@ __device__ inline int gram_exp_above(double v) {            // smallest e with |
 __global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                           GramHdr* __restrict__ hdr, int N, int D, int bclass,
                                                           float gscale) {
-  __shared__ float red[1024];
+  __shared__ float red[16][16];                              // [wave][value]
   __shared__ float r_sh[8];
-  const int tid = threadIdx.x;
-  auto block_max = [&](float v) {
-    red[tid] = v;
+  __shared__ float tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // max of NV values per thread over the block: wave shuffles, one LDS pass, results in tot[]
+  auto block_max_n = [&](float (&v)[16], int NV) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < NV) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] = fmaxf(v[i], __shfl_xor(v[i], off));
+      }
+    if (lane == 0)
+      for (int i = 0; i < NV; ++i) red[wave][i] = v[i];
     __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-      if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
-      __syncthreads();
+    if (tid < NV) {
+      float m = red[0][tid];
+      for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w][tid]);
+      tot[tid] = m;
     }
-    const float m = red[0];
     __syncthreads();
-    return m;
   };
   bool finite = true;
-  for (int i = 0; i < 8; ++i) {
-    float lo = 3.0e38f, hi = -3.0e38f;
-    if (i < D)
-      for (int k = tid; k < N; k += 1024) {
+  {
+    float mm[16];                                            // [0, 8): max_i, [8, 16): -min_i
+    for (int i = 0; i < 16; ++i) mm[i] = -3.0e38f;
+    for (int k = tid; k < N; k += 1024)
+      for (int i = 0; i < D && i < 8; ++i) {
         const float c = centers[(size_t)k * D + i];
         finite = finite && (fabsf(c) < 3.0e38f);
-        lo = fminf(lo, c); hi = fmaxf(hi, c);
+        mm[i] = fmaxf(mm[i], c);
+        mm[8 + i] = fmaxf(mm[8 + i], -c);
       }
-    const float mx = block_max(hi), mn = -block_max(-lo);
-    if (tid == 0) r_sh[i] = i < D ? 0.5f * mx + 0.5f * mn : 0.0f;
+    block_max_n(mm, 16);
+    if (tid < 8) r_sh[tid] = tid < D ? 0.5f * tot[tid] - 0.5f * tot[8 + tid] : 0.0f;
+    __syncthreads();
   }
-  __syncthreads();
   double cabs = 0.0, amax = 0.0, cmax = 0.0, c2max = 0.0;
   for (int k = tid; k < N; k += 1024) {
-    const double s2 = exp(-2.0 * (double)log_sigs[k]);
+    const double s2 = (double)expf(-2.0f * log_sigs[k]);     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280)
     double alpha, beta;
     if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(s2, gscale, alpha, beta);
     else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(s2, gscale, alpha, beta);
@@ -102,8 +115,11 @@ __global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restric
     c2max = fmax(c2max, fabs(alpha * n2 + beta));
     finite = finite && (fabs(alpha) < 1.0e30) && (amax == amax);
   }
-  const float fc = block_max((float)cabs), fa = block_max((float)amax), fC = block_max((float)cmax), f2 = block_max((float)c2max);
-  const float bad = block_max(finite ? 0.0f : 1.0f);
+  float st[16];
+  for (int i = 0; i < 16; ++i) st[i] = 0.0f;
+  st[0] = (float)cabs; st[1] = (float)amax; st[2] = (float)cmax; st[3] = (float)c2max; st[4] = finite ? 0.0f : 1.0f;
+  block_max_n(st, 5);
+  const float fc = tot[0], fa = tot[1], fC = tot[2], f2 = tot[3], bad = tot[4];
   if (tid == 0) {
     GramHdr h;
     for (int i = 0; i < 8; ++i) h.r[i] = r_sh[i];
@@ -140,8 +156,8 @@ __global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restric
 
 // v (|v| < 2^E) -> n0 (fixed point, grid 2^-10), n1, n2 (f16 values), v = 2^E (n0 + 2^-11 n1 + 2^-22 n2)
 __device__ inline void gram_parts_d(double v, int E, double (&n)[3]) {
-  const double a = ldexp(v, -E);
-  n[0] = rint(a * 1024.0) * (1.0 / 1024.0);
+  const double a = v * gram_pow2(-E);
+  n[0] = __builtin_rint(a * 1024.0) * (1.0 / 1024.0);
   const double r1 = (a - n[0]) * 2048.0;
   n[1] = (double)(_Float16)(float)r1;
   const double r2 = (r1 - n[1]) * 2048.0;
@@ -149,23 +165,25 @@ __device__ inline void gram_parts_d(double v, int E, double (&n)[3]) {
 }
 // c2: two fixed-point heads, two float tails
 __device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
-  const double a = ldexp(v, -E);
-  n[0] = rint(a * 1024.0) * (1.0 / 1024.0);
+  const double a = v * gram_pow2(-E);
+  n[0] = __builtin_rint(a * 1024.0) * (1.0 / 1024.0);
   const double r1 = (a - n[0]) * 2048.0;
-  n[1] = rint(r1 * 1024.0) * (1.0 / 1024.0);
+  n[1] = __builtin_rint(r1 * 1024.0) * (1.0 / 1024.0);
   const double r2 = (r1 - n[1]) * 2048.0;
   n[2] = (double)(_Float16)(float)r2;
   const double r3 = (r2 - n[2]) * 2048.0;
   n[3] = (double)(_Float16)(float)r3;
 }
 
-// one thread per (chunk, centre-in-chunk)
+// eight threads per (chunk, centre-in-chunk): thread `part` writes head slots 2 part, 2 part + 1, tail slots 8 part .. 8 part + 7 and
+// the W values of outputs 2 part, 2 part + 1 of every column tile (each recomputes the centre's parts: a few hundred operations)
 template <int BC>
 __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                         const float* __restrict__ kernel, const float* __restrict__ oscale,
                                                         const GramHdr* __restrict__ hdr, unsigned char* __restrict__ img, int N,
                                                         int K, int D, int O, int NT, float gscale, int nchunks) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = tix >> 3, part = tix & 7;
   if (idx >= nchunks * kF16Chunk) return;
   const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
   const int n = idx;
@@ -178,8 +196,8 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
   nA[0] = nA[1] = nA[2] = 0.0;
   n2[0] = n2[1] = n2[2] = n2[3] = 0.0;
   if (real && h.ok) {
-    const double s2 = exp(-2.0 * (double)log_sigs[n]);       // 1/sigma^2 (flax_rbf.py:280)
-    double alpha, beta;
+    const double s2 = (double)expf(-2.0f * log_sigs[n]);     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280); every term of
+    double alpha, beta;                                      // the expansion uses this one value: u = alpha |x - c|^2 + beta exactly
     gram_alpha_beta<BC>(s2, gscale, alpha, beta);
     double c2 = beta;
     for (int i = 0; i < D && i < kGramDims; ++i) {
@@ -198,12 +216,20 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
     if (sl.kind == 0) return (_Float16)0.0f;
     const int T = gram_T(h, sl);
     const int ac = T - gram_ax(T);
-    const double v = sl.kind == 1 ? nC[sl.dim][sl.q] : (sl.kind == 2 ? nA[sl.q] : n2[sl.p]);
-    return (_Float16)(float)ldexp(v, ac);
+    double v = 0.0;
+    if (sl.kind == 1) {                                      // dynamic dim index: select (the arrays stay in registers)
+      for (int i = 0; i < kGramDims; ++i)
+        if (i == sl.dim) v = sl.q == 0 ? nC[i][0] : (sl.q == 1 ? nC[i][1] : nC[i][2]);
+    } else if (sl.kind == 2) {
+      v = sl.q == 0 ? nA[0] : (sl.q == 1 ? nA[1] : nA[2]);
+    } else {
+      v = sl.p == 0 ? n2[0] : (sl.p == 1 ? n2[1] : (sl.p == 2 ? n2[2] : n2[3]));
+    }
+    return (_Float16)(float)(v * gram_pow2(ac));
   };
   _Float16* head = reinterpret_cast<_Float16*>(p + ct * 512);                  // lane (g, row): k = 4 g + j
-  for (int s = 0; s < 16; ++s) head[((s >> 2) * 16 + row) * 4 + (s & 3)] = cval(gram_head_slot(s));
-  for (int s = 0; s < 64; ++s) {
+  for (int s = 2 * part; s < 2 * part + 2; ++s) head[((s >> 2) * 16 + row) * 4 + (s & 3)] = cval(gram_head_slot(s));
+  for (int s = 8 * part; s < 8 * part + 8; ++s) {
     const int half = s >> 5, g = (s >> 3) & 3, j = s & 7;
     _Float16* tail = reinterpret_cast<_Float16*>(p + kGramHeadBytes + (ct * 2 + half) * 1024);
     tail[(g * 16 + row) * 8 + j] = cval(gram_tail_slot(s));
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
   for (int wt = 0; wt < NT; ++wt) {                          // column tiles of 16 outputs: W hi, W lo
     _Float16* wh = reinterpret_cast<_Float16*>(p + kGramOpBytes + (size_t)wt * 2 * kF16WBytes);
     _Float16* wl = wh + kF16WBytes / 2;
-    for (int oo = 0; oo < 16; ++oo) {
+    for (int oo = 2 * part; oo < 2 * part + 2; ++oo) {
       const int o = wt * 16 + oo;
       float w = 0.0f;
       if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
@@ -407,7 +433,7 @@ int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs
   hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(1024), 0, s, centers, log_sigs, hdr, net->N, net->D,
                      net->bclass, gauss_scale(net->basis));
   IRBFN_HIP_CHECK(hipGetLastError());
-  const int total = nchunks * kF16Chunk;
+  const int total = nchunks * kF16Chunk * 8;                 // eight threads per centre
   const dim3 grid((total + 255) / 256), block(256);
   const float gs = gauss_scale(net->basis);
   switch (net->bclass) {
@@ -417,9 +443,11 @@ int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
+  if (net->opt[IRBFN_OPT_GRAM_STICKY] != 0 && net->gram_checked) return IRBFN_OK;     // the first verdict stands (training loops)
   GramHdr h;
   IRBFN_HIP_CHECK(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, s));
   IRBFN_HIP_CHECK(hipStreamSynchronize(s));
+  net->gram_checked = 1;
   net->gram_ok = h.ok;
   net->gram_exp[0] = h.ex; net->gram_exp[1] = h.ec; net->gram_exp[2] = h.eq; net->gram_exp[3] = h.ea; net->gram_exp[4] = h.e2;
   return IRBFN_OK;

@@ -50,6 +50,9 @@ class TrainState:
         _lib.require_gpu()
         flat = distributed.flatten_params(distributed.params_to_device(params)).clone()
         st = cls(net, flat, lr, max_grad_norm, b1, b2, eps)
+        # a training loop re-binds the parameters every step: the matrix-core kernels' "do the parameters fit" verdict is read back
+        # for the first bind only (the kernels test the device-side verdict themselves; include/irbfn_hip.h, IRBFN_OPT_GRAM_STICKY)
+        net.set_options(gram_sticky=1)
         if opt_state is not None:
             st.m.copy_(distributed.flatten_params(distributed.params_to_device(opt_state[0])))
             st.v.copy_(distributed.flatten_params(distributed.params_to_device(opt_state[1])))
