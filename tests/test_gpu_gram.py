@@ -427,3 +427,43 @@ def test_vjp_gram_is_refused_where_the_expansion_is(gpu):
     with pytest.raises(ValueError, match="UNSUPPORTED"):
         net.vjp(orc.cast_params(P, np.float32), xt, torch.ones(x.shape[0], cfg["out_features"], device="cuda"))
     net.set_options(vjp_kernel=_lib.VJP_AUTO)
+
+
+def test_gram_sticky_verdict_costs_speed_never_correctness(gpu):
+    """IRBFN_OPT_GRAM_STICKY (training loops re-bind every step): only the first bind reads the pack's verdict back.  Parameters
+    that stop fitting the expansion behind a stale "fits" verdict are caught on the device -- every wave of K1g takes the VALU
+    distances, K2g hands over to K2h -- and the results stay right."""
+    import torch
+    rng = np.random.default_rng(21)
+    cfg, P = configs.model_card(2) | {"num_kernels": 256}, configs.synth_params(2)
+    P = {"params": {"rbf_list": {k: v[:, :256].copy() for k, v in P["params"]["rbf_list"].items()},
+                    "linear": {"kernel": P["params"]["linear"]["kernel"][:256].copy(), "bias": P["params"]["linear"]["bias"].copy()}}}
+    net = WCRBFNet.from_config(cfg)
+    B = 16384 + 5
+    x = configs.synth_queries(2, B=B)
+    g = rng.normal(size=(B, 10)).astype(np.float32)
+    net.apply(P, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<")
+    net.set_options(gram_sticky=1)
+    P2 = {"params": {"rbf_list": {"centers": P["params"]["rbf_list"]["centers"].copy(),
+                                  "log_sigs": np.full_like(P["params"]["rbf_list"]["log_sigs"], -7.0)},      # widths of 1e-3: outside the budget
+                     "linear": P["params"]["linear"]}}
+    P2["params"]["rbf_list"]["log_sigs"][0, :32] = 0.5                     # a few centres the queries still see
+    out = net.apply(P2, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram<")       # the stale verdict chose the kernel ...
+    p64 = orc.cast_params(P2, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    k1, _ = _run(net, P2, x, kernel=_lib.FWD_K1)
+    err, err_k1 = (np.abs(out - ref) / scale).max(), (np.abs(k1 - ref) / scale).max()
+    assert err <= max(3e-6, 2.0 * err_k1), (err, err_k1)                    # ... and the device-side test kept the result right
+    xt, gt = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    grads = net.vjp(P2, xt, gt)["params"]
+    gref = orc.wcrbfnet_vjp(cfg, p64, x.astype(np.float64), g.astype(np.float64))["params"]
+    for grp, name in LEAVES:
+        gr = np.asarray(gref[grp][name])
+        assert np.abs(grads[grp][name].cpu().numpy() - gr).max() <= 2e-5 * (np.abs(gr).max() + 1e-30), (grp, name)
+    net.set_options(gram_sticky=0)
+    net.bind(P)                                            # different parameters: re-packed, verdict read back again
+    net.apply(P2, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<")       # without the option the fresh verdict moves the net to K1h
