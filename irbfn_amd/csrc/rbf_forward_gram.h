@@ -15,6 +15,10 @@ constexpr int kGramOpBytes = kGramHeadBytes + kGramTailBytes;                   
 constexpr int gram_chunk_bytes(int NT = 1) { return kGramOpBytes + NT * 2 * kF16WBytes; }   // + W hi, W lo per column tile
 constexpr int kGramChunkBytes = gram_chunk_bytes(1);                              // 7 KiB (narrow nets)
 constexpr int kGramDims = 7;
+#ifndef IRBFN_GRAM_RING
+#define IRBFN_GRAM_RING 5       // chunk images per centre slice in the LDS ring of the narrow kernel: 3 (a barrier per chunk) or 5 (one per two)
+#endif
+constexpr int kGramRing = IRBFN_GRAM_RING;
 #ifndef IRBFN_GRAM_WAVES
 #define IRBFN_GRAM_WAVES 4     // waves per SIMD the register allocation must allow
 #endif

@@ -287,7 +287,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
   }
   // Ring of three chunk images per slice: during step i the waves read the distance operands of chunk i + 1 and the W
   // operands of chunk i while chunk i + 2 lands; one barrier per step, at its end.
-  unsigned char* ring = lds + (size_t)slice * 3 * CB;
+  unsigned char* ring = lds + (size_t)slice * kGramRing * CB;
   constexpr int NVI = CB / 1024;                             // 7 wave-instructions per chunk image
   auto stage = [&](int k, int buf) {                         // chunk c0 + k of the slice -> ring slot buf; the QG waves share the copy
     if (k >= na) return;
@@ -297,7 +297,22 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
       __builtin_amdgcn_global_load_lds((gptr_t)(gp + v * 1024), (lptr_t)(dst + v * 1024), 16, 0, 0);
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  auto next3 = [&](int b3) { return b3 == 2 ? 0 : b3 + 1; };
+  auto next3 = [&](int b3) { return b3 == kGramRing - 1 ? 0 : b3 + 1; };
+  // A step touches chunks i (W) and i + 1 (distance operands).  One barrier per kGramPer = (kGramRing - 1) / 2 steps: behind it chunks
+  // i + 1 .. i + kGramPer + 1 are resident and the next kGramPer are requested into the slots of the chunks everybody has left
+  // (kGramRing = 3: a barrier per chunk; 5: one per two chunks).
+  constexpr int kGramPer = (kGramRing - 1) / 2;
+  static_assert(kGramRing == 2 * kGramPer + 1 && kGramPer >= 1, "ring = 2 x (steps per barrier) + 1");
+  auto end_of_step = [&](int i, int b0) {
+    if ((i % kGramPer) != kGramPer - 1) return;
+    step_barrier();
+#pragma unroll
+    for (int j = 0; j < kGramPer; ++j) {
+      int slot = b0 - (kGramPer - 1) + j;                    // slot of chunk i - (kGramPer - 1) + j
+      slot = slot < 0 ? slot + kGramRing : slot;
+      stage(i + kGramPer + 2 + j, slot);
+    }
+  };
 
   f4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A1: ph * wh
   f4_t acl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                // A2: pls * wh + ph * wls
@@ -320,10 +335,11 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
     }
   };
 
-  stage(0, 0);
-  stage(1, 1);
-  step_barrier();                                            // chunks 0 and 1 are there
-  stage(2, 2);
+#pragma unroll
+  for (int k = 0; k <= kGramPer; ++k) stage(k, k);
+  step_barrier();                                            // the first kGramPer + 1 chunks are there
+#pragma unroll
+  for (int k = kGramPer + 1; k < kGramRing; ++k) stage(k, k);
   if (!wave_bad) {
     // two steps per trip: the distances of chunk i + 1 are issued in front of the VALU work on chunk i
     f4_t ua[2][2], ub[2][2];
@@ -342,12 +358,10 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
         products(t16, ring + b0 * CB, [&](float (&o)[16]) { trans16<BC>(ucur, o); });
       }
       [[maybe_unused]] const unsigned long long t2 = IRBFN_GRAM_T();
-      step_barrier();                                        // chunk i + 2 is there; everybody has left chunk i
-      [[maybe_unused]] const unsigned long long t3 = IRBFN_GRAM_T();
-      stage(i + 3, b0);
+      end_of_step(i, b0);
       [[maybe_unused]] const unsigned long long t4 = IRBFN_GRAM_T();
 #ifdef IRBFN_GRAM_STAMPS
-      tph[1] += t2 - t0; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += 1;
+      tph[1] += t2 - t0; tph[2] += t4 - t2; tph[4] += 1;
 #endif
       b0 = b1;
     };
@@ -369,8 +383,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
         gram_valu_args<DC, BC>(a, qrow, g, reinterpret_cast<const float*>(a.img + (size_t)(c0 + i) * CBL), t16);
         products(t16, ring + b0 * CB, [&](float (&o)[16]) { trans_block<BC, 16>(o); });
       }
-      step_barrier();
-      stage(i + 3, b0);
+      end_of_step(i, b0);
       b0 = next3(b0);
     }
   }
@@ -495,7 +508,7 @@ int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, i
   a.gimg = net->gram_img;
   a.hdr = reinterpret_cast<const GramHdr*>(net->gram_hdr);
   const int waves = S * QG;
-  const size_t ring = (size_t)S * 3 * kGramChunkBytes;
+  const size_t ring = (size_t)S * kGramRing * kGramChunkBytes;
   const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32) * sizeof(float);
   const size_t lds = ring > red ? ring : red;
   if (lds > 160 * 1024) return IRBFN_ERR_UNSUPPORTED;
@@ -552,7 +565,7 @@ int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int*
   gram_geometry(net, B, &S, &QG);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   const int waves = S * QG;
-  const size_t ring = (size_t)S * 3 * kGramChunkBytes;
+  const size_t ring = (size_t)S * kGramRing * kGramChunkBytes;
   const size_t red = ((size_t)waves * 2 * 4 * 64 + (size_t)QG * 32 + (size_t)QG * 32 * (kTickNarrowCP + kTickNarrowSP)) * sizeof(float);
   const size_t lds = ring > red ? ring : red;
   if (lds > 160 * 1024 || S > nchunks) return IRBFN_ERR_UNSUPPORTED;

@@ -11,7 +11,7 @@ cfg, P = configs.model_card(2), configs.synth_params(2)
 net = WCRBFNet.from_config(cfg); net.bind(distributed.params_to_device(P))
 x = torch.from_numpy(configs.synth_queries(2)).cuda()
 out = []
-for S, QG in ((2, 8), (1, 16), (4, 4), (1, 8), (2, 4), (1, 4)):
+for S, QG in ((2, 4), (1, 4), (1, 8), (2, 2), (4, 2)):
     net.set_options(fwd_kernel=_lib.FWD_K1G, fwd_f16_s=S, fwd_f16_qg=QG)
     try:
         out.append(f"S={S} QG={QG}: {min(t_us(lambda: net(x)) for _ in range(3)):.1f}")
