@@ -29,7 +29,7 @@
 // query (l & 15) of its wave's two query tiles; the D registers of centre tile ct hold centres 16 ct + 4 g + r (g = l >> 4),
 // which become k-slots 8 g + 4 ct + r of the Phi x W product (the W rows of the image are permuted to match).
 // Chunk image (32 centres, 7 KiB): head operands [ct][lane] 8 B, tail operands [ct][half][lane] 16 B, W hi, W lo (1 KiB each);
-// the QG waves of a centre slice share an LDS ring of three images filled by LDS-DMA, one barrier per chunk.
+// the QG waves of a centre slice share an LDS ring of five images filled by LDS-DMA, one barrier per two chunks.
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -285,8 +285,8 @@ __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl,
     const int m = (int)((long)a.nchunks * (s2 + 1) / S) - (int)((long)a.nchunks * s2 / S);
     nsteps = m > nsteps ? m : nsteps;
   }
-  // Ring of three chunk images per slice: during step i the waves read the distance operands of chunk i + 1 and the W
-  // operands of chunk i while chunk i + 2 lands; one barrier per step, at its end.
+  // Ring of kGramRing chunk images per slice: during step i the waves read the distance operands of chunk i + 1 and the W
+  // operands of chunk i while later chunks land (end_of_step below).
   unsigned char* ring = lds + (size_t)slice * kGramRing * CB;
   constexpr int NVI = CB / 1024;                             // 7 wave-instructions per chunk image
   auto stage = [&](int k, int buf) {                         // chunk c0 + k of the slice -> ring slot buf; the QG waves share the copy

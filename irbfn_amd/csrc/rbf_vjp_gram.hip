@@ -173,8 +173,11 @@ struct VjpGArgs {
   float gscale;
 };
 
+#ifndef IRBFN_K2G_WAVES
+#define IRBFN_K2G_WAVES 4       // waves per SIMD the register allocation must allow (3: 138 VGPRs, 206 us at config 3; 4: 128 VGPRs + 9 spilled, 200 us)
+#endif
 template <int DC, int BC>
-__global__ __launch_bounds__(256, 3) void rbf_vjp_f16gram(const VjpGArgs a) {
+__global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   if (*a.flag != 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
