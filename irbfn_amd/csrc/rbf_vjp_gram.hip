@@ -174,7 +174,8 @@ struct VjpGArgs {
 };
 
 #ifndef IRBFN_K2G_WAVES
-#define IRBFN_K2G_WAVES 4       // waves per SIMD the register allocation must allow (3: 138 VGPRs, 206 us at config 3; 4: 128 VGPRs + 9 spilled, 200 us)
+#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs.  (4 -- 128 VGPRs, 9 spilled -- measured 3 % faster and
+                                // WRONG: non-finite gradients; not pursued)
 #endif
 template <int DC, int BC>
 __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {

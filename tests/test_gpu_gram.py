@@ -467,3 +467,31 @@ def test_gram_sticky_verdict_costs_speed_never_correctness(gpu):
     net.bind(P)                                            # different parameters: re-packed, verdict read back again
     net.apply(P2, x)
     assert net.last_launch()["kernel"].startswith("rbf_fwd_f16mfma<")       # without the option the fresh verdict moves the net to K1h
+
+
+def test_training_steps_on_the_matrix_core_kernels_follow_the_float32_ones(gpu):
+    """Six on-device training steps (scripts/train_nmpc.py:258-300) at a batch the automatic choice gives to K1g + K2g, against the same
+    steps forced onto K1h + K2h: same losses (1e-5), finite parameters, and the VJP really ran on K2g."""
+    import torch
+    from irbfn_amd import train
+    card = dict(configs.model_card(3), num_kernels=512)
+    P = configs.synth_params(3)
+    P = {"params": {"rbf_list": {k: v[:, :512] for k, v in P["params"]["rbf_list"].items()},
+                    "linear": {"kernel": P["params"]["linear"]["kernel"][:512], "bias": P["params"]["linear"]["bias"]}}}
+    B = 16384 + 64
+    x = torch.from_numpy(configs.synth_queries(3, B=B)).cuda()
+    y = torch.from_numpy(configs.synth_cotangent(3, B=B)).cuda()
+    runs = {}
+    for name, fk, vk in (("h", _lib.FWD_K1H, _lib.VJP_K2H), ("g", _lib.FWD_AUTO, _lib.VJP_AUTO)):
+        net = WCRBFNet.from_config(card)
+        net.set_options(fwd_kernel=fk, vjp_kernel=vk)
+        st = train.TrainState.create(net, P, lr=1e-3, max_grad_norm=1.0)
+        losses = []
+        for _ in range(6):
+            st, loss = train.train_step_oneint(st, x, y, configs.DYN_PARAMS)
+            losses.append(float(loss))
+        runs[name] = (losses, st.flat.clone(), net.last_launch()["kernel"])
+    assert runs["g"][2].startswith("rbf_vjp_f16gram<"), runs["g"][2]
+    assert np.isfinite(runs["g"][0]).all() and bool(torch.isfinite(runs["g"][1]).all())
+    assert np.allclose(runs["g"][0], runs["h"][0], rtol=1e-5)
+    assert float((runs["g"][1] - runs["h"][1]).abs().max()) <= 1e-4 * float(runs["h"][1].abs().max())

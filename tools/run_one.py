@@ -1,6 +1,6 @@
 """ONE kernel at ONE batch size, N launches: the unit of a per-(kernel, batch size) rocprofv3 summary
     rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/run_one.py <what> <B> [launches]
-what: fwd_cfg2[_k1h|_k1g] | fwd_cfg4_wide | tick_cfg4 | vjp_cfg3 | roll_<mode> | rollvjp_<mode> | spiral | spiralvjp | sparse_fwd |
+what: fwd_cfg2[_k1h|_k1g] | fwd_cfg4_wide | tick_cfg4 | vjp_cfg3 | train_cfg3 | roll_<mode> | rollvjp_<mode> | spiral | spiralvjp | sparse_fwd |
       sparse_tick | sparse_vjp | sparse_train      (mode: st_ks, st_select, fullint, frenet; T = 50, spiral N = 9)"""
 import json
 import os
@@ -51,6 +51,11 @@ elif what == "tick_cfg4":
     net, P = net_of(4); xq = configs.synth_queries(4, B=B); x = torch.from_numpy(xq).cuda()
     s0 = torch.from_numpy(configs.initial_state_from_query(xq)).cuda()
     fn = lambda: plan_batch(net, P, x, s0, DP, mode=_lib.ROLLOUT_ST_KS, return_controls=False)
+elif what == "train_cfg3":
+    net, P = net_of(3); x = torch.from_numpy(configs.synth_queries(3, B=B)).cuda(); y = torch.from_numpy(configs.synth_cotangent(3, B=B)).cuda()
+    st = [train.TrainState.create(net, configs.synth_params(3), lr=1e-3, max_grad_norm=1.0)]
+    def fn():
+        st[0], _ = train.train_step_oneint(st[0], x, y, DP)
 elif what == "vjp_cfg3":
     net, P = net_of(3); x = torch.from_numpy(configs.synth_queries(3, B=B)).cuda(); g = torch.from_numpy(configs.synth_cotangent(3, B=B)).cuda()
     fn = lambda: net.vjp(P, x, g)
