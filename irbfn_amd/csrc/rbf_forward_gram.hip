@@ -82,44 +82,49 @@ __global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restric
     }
     __syncthreads();
   };
+  // ONE pass: per coordinate max and -min of the centres (origin = midpoint, half widths), the largest |alpha|, finiteness.  The
+  // bounds on C = -2 alpha c' and on c2 = alpha |c'|^2 + beta are products of these maxima (at most the true maxima x the spread
+  // of alpha over the centres: a coarser grid where it matters, never a wrong one) -- a second pass over the centres with the
+  // origin known would make them tight at twice the kernel time, and this kernel runs at every irbfn_net_set_params.
   bool finite = true;
-  {
-    float mm[16];                                            // [0, 8): max_i, [8, 16): -min_i
-    for (int i = 0; i < 16; ++i) mm[i] = -3.0e38f;
-    for (int k = tid; k < N; k += 1024)
-      for (int i = 0; i < D && i < 8; ++i) {
-        const float c = centers[(size_t)k * D + i];
-        finite = finite && (fabsf(c) < 3.0e38f);
-        mm[i] = fmaxf(mm[i], c);
-        mm[8 + i] = fmaxf(mm[8 + i], -c);
-      }
-    block_max_n(mm, 16);
-    if (tid < 8) r_sh[tid] = tid < D ? 0.5f * tot[tid] - 0.5f * tot[8 + tid] : 0.0f;
-    __syncthreads();
-  }
-  double cabs = 0.0, amax = 0.0, cmax = 0.0, c2max = 0.0;
+  float mm[16];                                              // [0, 8): max_i, [8, 16): -min_i
+  for (int i = 0; i < 16; ++i) mm[i] = -3.0e38f;
+  float am = 0.0f;
   for (int k = tid; k < N; k += 1024) {
+    for (int i = 0; i < D && i < 8; ++i) {
+      const float c = centers[(size_t)k * D + i];
+      finite = finite && (fabsf(c) < 3.0e38f);
+      mm[i] = fmaxf(mm[i], c);
+      mm[8 + i] = fmaxf(mm[8 + i], -c);
+    }
     const double s2 = (double)expf(-2.0f * log_sigs[k]);     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280)
     double alpha, beta;
     if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(s2, gscale, alpha, beta);
     else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(s2, gscale, alpha, beta);
     else gram_alpha_beta<BC_IMQ>(s2, gscale, alpha, beta);
-    double n2 = 0.0;
-    for (int i = 0; i < D; ++i) {
-      const double cp = (double)centers[(size_t)k * D + i] - (double)r_sh[i];
-      cabs = fmax(cabs, fabs(cp));
-      cmax = fmax(cmax, fabs(2.0 * alpha * cp));
-      n2 += cp * cp;
+    const float fa1 = (float)fabs(alpha);
+    finite = finite && (fa1 < 1.0e30f);
+    am = fmaxf(am, fa1);
+  }
+  block_max_n(mm, 16);
+  float hw2 = 0.0f, hwm = 0.0f;                              // sum of the squared half widths, largest half width
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) {
+      r_sh[i] = i < D ? 0.5f * tot[i] - 0.5f * tot[8 + i] : 0.0f;
+      const float hw = i < D ? fmaxf(tot[i] - r_sh[i], r_sh[i] + tot[8 + i]) * 1.0000005f : 0.0f;     // the rounded midpoint's two sides
+      hw2 += hw * hw;
+      hwm = fmaxf(hwm, hw);
     }
-    amax = fmax(amax, fabs(alpha));
-    c2max = fmax(c2max, fabs(alpha * n2 + beta));
-    finite = finite && (fabs(alpha) < 1.0e30) && (amax == amax);
   }
   float st[16];
   for (int i = 0; i < 16; ++i) st[i] = 0.0f;
-  st[0] = (float)cabs; st[1] = (float)amax; st[2] = (float)cmax; st[3] = (float)c2max; st[4] = finite ? 0.0f : 1.0f;
-  block_max_n(st, 5);
-  const float fc = tot[0], fa = tot[1], fC = tot[2], f2 = tot[3], bad = tot[4];
+  st[0] = am; st[1] = finite ? 0.0f : 1.0f;
+  block_max_n(st, 2);
+  double beta0, alpha0;
+  if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(1.0, gscale, alpha0, beta0);
+  else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(1.0, gscale, alpha0, beta0);
+  else gram_alpha_beta<BC_IMQ>(1.0, gscale, alpha0, beta0);
+  const float fc = hwm, fa = tot[0], fC = 2.0f * tot[0] * hwm, f2 = tot[0] * hw2 + (float)fabs(beta0), bad = tot[1];
   if (tid == 0) {
     GramHdr h;
     for (int i = 0; i < 8; ++i) h.r[i] = r_sh[i];
@@ -175,8 +180,9 @@ __device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
   n[3] = (double)(_Float16)(float)r3;
 }
 
-// eight threads per (chunk, centre-in-chunk): thread `part` writes head slots 2 part, 2 part + 1, tail slots 8 part .. 8 part + 7 and
-// the W values of outputs 2 part, 2 part + 1 of every column tile (each recomputes the centre's parts: a few hundred operations)
+// eight threads per (chunk, centre-in-chunk): thread `part` < 7 writes the slots of coordinate `part` (1 head, 5 tails), thread 7 the
+// slots of Q x alpha and of c2 (3 heads, 7 tails) and the empty ones; every thread the W values of outputs 2 part, 2 part + 1 of
+// every column tile
 template <int BC>
 __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                         const float* __restrict__ kernel, const float* __restrict__ oscale,
@@ -191,48 +197,50 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
   const GramHdr h = *hdr;
   unsigned char* p = img + (size_t)c * gram_chunk_bytes(NT);
   const int ct = kk >> 4, row = kk & 15;                     // centre tile, A-operand row
-  double nC[kGramDims][3], nA[3], n2[4];
-  for (int i = 0; i < kGramDims; ++i) nC[i][0] = nC[i][1] = nC[i][2] = 0.0;
-  nA[0] = nA[1] = nA[2] = 0.0;
-  n2[0] = n2[1] = n2[2] = n2[3] = 0.0;
-  if (real && h.ok) {
-    const double s2 = (double)expf(-2.0f * log_sigs[n]);     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280); every term of
-    double alpha, beta;                                      // the expansion uses this one value: u = alpha |x - c|^2 + beta exactly
-    gram_alpha_beta<BC>(s2, gscale, alpha, beta);
-    double c2 = beta;
-    for (int i = 0; i < D && i < kGramDims; ++i) {
-      const double cp = (double)centers[(size_t)n * D + i] - (double)h.r[i];
-      gram_parts_d(-2.0 * alpha * cp, h.ec, nC[i]);
-      c2 += alpha * cp * cp;
-    }
-    gram_parts_d(alpha, h.ea, nA);
-    gram_parts_c2(c2, h.e2, n2);
-  } else if (h.ok) {
-    double alpha, beta;                                      // a padding centre: u = beta (P finite), its W rows are 0
-    gram_alpha_beta<BC>(1.0, gscale, alpha, beta);
-    gram_parts_c2(beta, h.e2, n2);
-  }
-  auto cval = [&](const GramSlot sl) -> _Float16 {
-    if (sl.kind == 0) return (_Float16)0.0f;
-    const int T = gram_T(h, sl);
-    const int ac = T - gram_ax(T);
-    double v = 0.0;
-    if (sl.kind == 1) {                                      // dynamic dim index: select (the arrays stay in registers)
-      for (int i = 0; i < kGramDims; ++i)
-        if (i == sl.dim) v = sl.q == 0 ? nC[i][0] : (sl.q == 1 ? nC[i][1] : nC[i][2]);
-    } else if (sl.kind == 2) {
-      v = sl.q == 0 ? nA[0] : (sl.q == 1 ? nA[1] : nA[2]);
-    } else {
-      v = sl.p == 0 ? n2[0] : (sl.p == 1 ? n2[1] : (sl.p == 2 ? n2[2] : n2[3]));
-    }
-    return (_Float16)(float)(v * gram_pow2(ac));
-  };
   _Float16* head = reinterpret_cast<_Float16*>(p + ct * 512);                  // lane (g, row): k = 4 g + j
-  for (int s = 2 * part; s < 2 * part + 2; ++s) head[((s >> 2) * 16 + row) * 4 + (s & 3)] = cval(gram_head_slot(s));
-  for (int s = 8 * part; s < 8 * part + 8; ++s) {
+  auto put_head = [&](int s, double v, int T) { head[((s >> 2) * 16 + row) * 4 + (s & 3)] = (_Float16)(float)(v * gram_pow2(T - gram_ax(T))); };
+  auto put_tail = [&](int s, double v, int T) {
     const int half = s >> 5, g = (s >> 3) & 3, j = s & 7;
     _Float16* tail = reinterpret_cast<_Float16*>(p + kGramHeadBytes + (ct * 2 + half) * 1024);
-    tail[(g * 16 + row) * 8 + j] = cval(gram_tail_slot(s));
+    tail[(g * 16 + row) * 8 + j] = (_Float16)(float)(v * gram_pow2(T - gram_ax(T)));
+  };
+  double alpha = 0.0, beta = 0.0;
+  if (h.ok) {
+    const double s2 = real ? (double)expf(-2.0f * log_sigs[n]) : 1.0;     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280); every
+    gram_alpha_beta<BC>(s2, gscale, alpha, beta);                          // term of the expansion uses this one value
+    if (!real) alpha = 0.0;                                  // a padding centre: u = beta (P finite), its W rows are 0
+  }
+  if (part < kGramDims) {
+    double nC[3] = {0.0, 0.0, 0.0};
+    if (real && h.ok && part < D) gram_parts_d(-2.0 * alpha * ((double)centers[(size_t)n * D + part] - (double)h.r[part]), h.ec, nC);
+    put_head(part, nC[0], h.ex + h.ec);
+    for (int m = 0; m < 5; ++m) {
+      const int q = gram_comb_q(m);
+      put_tail(5 * part + m, nC[q], h.ex + h.ec - 11 * (gram_comb_p(m) + q));
+    }
+  } else {
+    double nA[3] = {0.0, 0.0, 0.0}, n2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (h.ok) {
+      double c2 = beta;
+      if (real)
+        for (int i = 0; i < D && i < kGramDims; ++i) {
+          const double cp = (double)centers[(size_t)n * D + i] - (double)h.r[i];
+          c2 += alpha * cp * cp;
+        }
+      gram_parts_d(alpha, h.ea, nA);
+      gram_parts_c2(c2, h.e2, n2);
+    }
+    put_head(7, nA[0], h.eq + h.ea);
+    put_head(8, n2[0], h.e2);
+    put_head(9, n2[1], h.e2 - 11);
+    for (int s = 10; s < 16; ++s) put_head(s, 0.0, 0);
+    for (int m = 0; m < 5; ++m) {
+      const int q = gram_comb_q(m);
+      put_tail(5 * kGramDims + m, nA[q], h.eq + h.ea - 11 * (gram_comb_p(m) + q));
+    }
+    put_tail(5 * kGramDims + 5, n2[2], h.e2 - 22);
+    put_tail(5 * kGramDims + 6, n2[3], h.e2 - 33);
+    for (int s = 5 * kGramDims + 7; s < 64; ++s) put_tail(s, 0.0, 0);
   }
   // W rows in the k order of the Phi x W product: centre 16 ct + 4 g + r <-> k = 8 g + 4 ct + r
   const int g = row >> 2, j = ct * 4 + (row & 3);
