@@ -329,9 +329,9 @@ bool gram_preferred(const irbfn_net* net, int64_t B) {
   return net->gram_img && net->gram_ok && net->O <= 16 && (ot == 3 || ot == 0) && B >= 12288;
 }
 
-// K1g for wide outputs (rbf_forward_gram_wide.hip): d = 7, the parameters fit the expansion
+// K1g for wide outputs (rbf_forward_gram_wide.hip): d = 7 or 8, the parameters fit the expansion
 bool gram_wide_preferred(const irbfn_net* net, int64_t B) {
-  return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && net->DC == 7 && B >= 2048;
+  return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && (net->DC == 7 || net->DC == 8) && B >= 2048;
 }
 
 // S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (21 KiB of LDS per

@@ -14,7 +14,7 @@ constexpr int kGramTailBytes = 2 * 2 * 64 * 16;                  // [ct][half][l
 constexpr int kGramOpBytes = kGramHeadBytes + kGramTailBytes;                     // 5 KiB of distance operands per chunk
 constexpr int gram_chunk_bytes(int NT = 1) { return kGramOpBytes + NT * 2 * kF16WBytes; }   // + W hi, W lo per column tile
 constexpr int kGramChunkBytes = gram_chunk_bytes(1);                              // 7 KiB (narrow nets)
-constexpr int kGramDims = 7;
+constexpr int kGramDims = 8;                                    // coordinates the slot tables hold (d <= 8: the Frenet nets have 8)
 #ifndef IRBFN_GRAM_RING
 #define IRBFN_GRAM_RING 5       // chunk images per centre slice in the LDS ring of the narrow kernel: 3 (a barrier per chunk) or 5 (one per two)
 #endif
@@ -34,7 +34,8 @@ struct GramHdr {
 struct GramSlot { int kind, dim, p, q; };        // kind: 0 empty, 1 x'_dim part p x C part q, 2 Q part p x alpha part q, 3 1 x c2 part p
 __host__ __device__ constexpr GramSlot gram_head_slot(int s) {
   return s < kGramDims ? GramSlot{1, s, 0, 0}
-                       : (s == 7 ? GramSlot{2, 0, 0, 0} : (s == 8 ? GramSlot{3, 0, 0, 0} : (s == 9 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})));
+                       : (s == kGramDims ? GramSlot{2, 0, 0, 0}
+                                         : (s == kGramDims + 1 ? GramSlot{3, 0, 0, 0} : (s == kGramDims + 2 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})));
 }
 __host__ __device__ constexpr int gram_comb_p(int m) { return m == 0 ? 0 : (m == 1 ? 1 : (m == 2 ? 0 : (m == 3 ? 2 : 1))); }
 __host__ __device__ constexpr int gram_comb_q(int m) { return m == 0 ? 1 : (m == 1 ? 0 : (m == 2 ? 2 : (m == 3 ? 0 : 1))); }
@@ -125,7 +126,7 @@ __device__ __forceinline__ void gram_parts_f(float vh, float vl, float inv, floa
 template <int DC>
 __device__ __forceinline__ bool gram_query_operands(const F16Args& a, const GramHdr* hp, const long (&qrow)[2], int g, h4_t (&bhd)[2],
                                                     h8_t (&btl)[2][2]) {
-  static_assert(DC <= kGramDims, "seven coordinate slots");
+  static_assert(DC <= kGramDims, "eight coordinate slots");
   const int ex = hp->ex, ec = hp->ec, eq = hp->eq, ea = hp->ea, e2 = hp->e2;
   GramHdr hx;                                                // exponents only (gram_T)
   hx.ex = ex; hx.ec = ec; hx.eq = eq; hx.ea = ea; hx.e2 = e2;

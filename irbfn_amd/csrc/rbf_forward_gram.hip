@@ -180,16 +180,18 @@ __device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
   n[3] = (double)(_Float16)(float)r3;
 }
 
-// eight threads per (chunk, centre-in-chunk): thread `part` < 7 writes the slots of coordinate `part` (1 head, 5 tails), thread 7 the
-// slots of Q x alpha and of c2 (3 heads, 7 tails) and the empty ones; every thread the W values of outputs 2 part, 2 part + 1 of
-// every column tile
+// sixteen threads per (chunk, centre-in-chunk): thread `part` < 8 writes the slots of coordinate `part` (1 head, 5 tails), thread 8
+// the slots of Q x alpha and of c2 (3 heads, 7 tails) and the empty ones; every thread the W values of output `part` of every
+// column tile
+constexpr int kGramPackThreads = 16;
+static_assert(kGramDims + 1 <= kGramPackThreads && kGramDims + 3 <= 16 && 5 * kGramDims + 7 <= 64, "slots of the expansion");
 template <int BC>
 __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
                                                         const float* __restrict__ kernel, const float* __restrict__ oscale,
                                                         const GramHdr* __restrict__ hdr, unsigned char* __restrict__ img, int N,
                                                         int K, int D, int O, int NT, float gscale, int nchunks) {
   const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-  const int idx = tix >> 3, part = tix & 7;
+  const int idx = tix / kGramPackThreads, part = tix % kGramPackThreads;
   if (idx >= nchunks * kF16Chunk) return;
   const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
   const int n = idx;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
       const int q = gram_comb_q(m);
       put_tail(5 * part + m, nC[q], h.ex + h.ec - 11 * (gram_comb_p(m) + q));
     }
-  } else {
+  } else if (part == kGramDims) {
     double nA[3] = {0.0, 0.0, 0.0}, n2[4] = {0.0, 0.0, 0.0, 0.0};
     if (h.ok) {
       double c2 = beta;
@@ -230,10 +232,10 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
       gram_parts_d(alpha, h.ea, nA);
       gram_parts_c2(c2, h.e2, n2);
     }
-    put_head(7, nA[0], h.eq + h.ea);
-    put_head(8, n2[0], h.e2);
-    put_head(9, n2[1], h.e2 - 11);
-    for (int s = 10; s < 16; ++s) put_head(s, 0.0, 0);
+    put_head(kGramDims, nA[0], h.eq + h.ea);
+    put_head(kGramDims + 1, n2[0], h.e2);
+    put_head(kGramDims + 2, n2[1], h.e2 - 11);
+    for (int s = kGramDims + 3; s < 16; ++s) put_head(s, 0.0, 0);
     for (int m = 0; m < 5; ++m) {
       const int q = gram_comb_q(m);
       put_tail(5 * kGramDims + m, nA[q], h.eq + h.ea - 11 * (gram_comb_p(m) + q));
@@ -247,15 +249,13 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
   for (int wt = 0; wt < NT; ++wt) {                          // column tiles of 16 outputs: W hi, W lo
     _Float16* wh = reinterpret_cast<_Float16*>(p + kGramOpBytes + (size_t)wt * 2 * kF16WBytes);
     _Float16* wl = wh + kF16WBytes / 2;
-    for (int oo = 2 * part; oo < 2 * part + 2; ++oo) {
-      const int o = wt * 16 + oo;
-      float w = 0.0f;
-      if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
-      _Float16 hh, ll;
-      split_static_f16(w, hh, ll);
-      wh[(g * 16 + oo) * 8 + j] = hh;
-      wl[(g * 16 + oo) * 8 + j] = ll;
-    }
+    const int oo = part, o = wt * 16 + oo;
+    float w = 0.0f;
+    if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
+    _Float16 hh, ll;
+    split_static_f16(w, hh, ll);
+    wh[(g * 16 + oo) * 8 + j] = hh;
+    wl[(g * 16 + oo) * 8 + j] = ll;
   }
 }
 
@@ -454,7 +454,7 @@ int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs
   hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(1024), 0, s, centers, log_sigs, hdr, net->N, net->D,
                      net->bclass, gauss_scale(net->basis));
   IRBFN_HIP_CHECK(hipGetLastError());
-  const int total = nchunks * kF16Chunk * 8;                 // eight threads per centre
+  const int total = nchunks * kF16Chunk * kGramPackThreads;
   const dim3 grid((total + 255) / 256), block(256);
   const float gs = gauss_scale(net->basis);
   switch (net->bclass) {
@@ -527,6 +527,7 @@ int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, i
     case 3: rc = launch_gram_bc<3>(a, net->bclass, grid, waves * 64, lds, s); break;
     case 4: rc = launch_gram_bc<4>(a, net->bclass, grid, waves * 64, lds, s); break;
     case 7: rc = launch_gram_bc<7>(a, net->bclass, grid, waves * 64, lds, s); break;
+    case 8: rc = launch_gram_bc<8>(a, net->bclass, grid, waves * 64, lds, s); break;
     default: rc = IRBFN_ERR_UNSUPPORTED;
   }
   if (rc == IRBFN_OK) {
@@ -566,9 +567,10 @@ static int launch_tick_gram_bc(const GramArgs& a, const F16Roll& rl, int mode, i
 int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0, const DynParams& dp,
                             float* controls, float* states, int64_t B, int T, hipStream_t s) {
   if (net->opt[IRBFN_OPT_FWD_KERNEL] != IRBFN_FWD_AUTO && net->opt[IRBFN_OPT_FWD_KERNEL] != IRBFN_FWD_K1G) return IRBFN_ERR_UNSUPPORTED;
-  if (!gram_preferred(net, B) || net->DC != 7) return IRBFN_ERR_UNSUPPORTED;
+  if (!gram_preferred(net, B)) return IRBFN_ERR_UNSUPPORTED;
   if (net->opt[IRBFN_OPT_TICK_FUSED] == 0 || net->O != 2 * T || T > kTickNarrowT) return IRBFN_ERR_UNSUPPORTED;
-  if (mode != IRBFN_ROLLOUT_ST_SELECT && mode != IRBFN_ROLLOUT_ST_KS && mode != IRBFN_ROLLOUT_FULLINT) return IRBFN_ERR_UNSUPPORTED;
+  const bool st = mode == IRBFN_ROLLOUT_ST_SELECT || mode == IRBFN_ROLLOUT_ST_KS || mode == IRBFN_ROLLOUT_FULLINT;
+  if (!((st && net->DC == 7) || (mode == IRBFN_ROLLOUT_FRENET_LS && net->DC == 8))) return IRBFN_ERR_UNSUPPORTED;
   int S, QG;
   gram_geometry(net, B, &S, &QG);
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
@@ -586,7 +588,8 @@ int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int*
   rl.state0 = state0; rl.states = states; rl.mirror = mirror; rl.T = T; rl.wlds = 0; rl.dp = dp;
   const long groups = (B + 31) / 32;
   const int grid = (int)((groups + QG - 1) / QG);
-  const int rc = launch_tick_gram_bc<7>(a, rl, mode, net->bclass, grid, waves * 64, lds, s);
+  const int rc = net->DC == 7 ? launch_tick_gram_bc<7>(a, rl, mode, net->bclass, grid, waves * 64, lds, s)
+                              : launch_tick_gram_bc<8>(a, rl, mode, net->bclass, grid, waves * 64, lds, s);
   if (rc == IRBFN_OK) {
     snprintf(net->last_name, sizeof(net->last_name), "rbf_tick_f16gram<D=%d,BC=%d,MODE=%d,S=%d,QG=%d>", net->DC, net->bclass, mode, S, QG);
     net->last_grid = grid;

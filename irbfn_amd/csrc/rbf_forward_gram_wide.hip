@@ -1,4 +1,4 @@
-// K1g for wide outputs (16 < O <= 128, d = 7): rbf_fwd_f16gram_wide -- see rbf_forward_gram_wide.h (the body) and
+// K1g for wide outputs (16 < O <= 128, d = 7 or 8): rbf_fwd_f16gram_wide -- see rbf_forward_gram_wide.h (the body) and
 // rbf_forward_gram.hip (the expansion, its accuracy argument, the pack).  Same mathematics as K1 / K1h
 // (src/irbfn_mpc/model.py:169-198; RBF stage flax_rbf.py:258-285).
 #include <stdio.h>
@@ -13,11 +13,11 @@ __global__ __launch_bounds__(512) void rbf_fwd_f16gram_wide(const GramArgs ga) {
   wide_gram_body<DC, BC, NT, -1>(ga, F16Roll{}, lds);
 }
 
-template <int NT>
+template <int DC, int NT>
 static int launch_gw_bc(const GramArgs& a, int bc, int grid, int block, size_t lds, hipStream_t s) {
 #define IRBFN_GWCASE(BCV)                                                                                     \
   case BCV: {                                                                                                 \
-    auto k = rbf_fwd_f16gram_wide<7, BCV, NT>;                                                                \
+    auto k = rbf_fwd_f16gram_wide<DC, BCV, NT>;                                                                \
     if (lds > 48 * 1024) {                                                                                    \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -72,7 +72,7 @@ void gram_fill_args(const irbfn_net* net, const float* x, float* out, int64_t B,
 }
 
 int launch_forward_gram_wide(irbfn_net* net, const float* x, float* out, int64_t B, int SW, int QG, hipStream_t s) {
-  if (!net->gram_img || !net->f16_img || net->DC != 7 || net->O <= 16 || net->O > 128) return IRBFN_ERR_UNSUPPORTED;
+  if (!net->gram_img || !net->f16_img || (net->DC != 7 && net->DC != 8) || net->O <= 16 || net->O > 128) return IRBFN_ERR_UNSUPPORTED;
   const int NT = (net->O + 15) / 16;
   gram_wide_geometry(net, B, &SW, &QG);
   GramArgs a;
@@ -82,18 +82,21 @@ int launch_forward_gram_wide(irbfn_net* net, const float* x, float* out, int64_t
   const long groups = (B + 31) / 32;
   const int grid = (int)((groups + QG - 1) / QG);
   int rc;
-  switch (NT) {
-    case 2: rc = launch_gw_bc<2>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 3: rc = launch_gw_bc<3>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 4: rc = launch_gw_bc<4>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 5: rc = launch_gw_bc<5>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 6: rc = launch_gw_bc<6>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 7: rc = launch_gw_bc<7>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    case 8: rc = launch_gw_bc<8>(a, net->bclass, grid, SW * QG * 64, lds, s); break;
-    default: rc = IRBFN_ERR_UNSUPPORTED;
+#define IRBFN_GW_NT(DCV)                                                                      \
+  switch (NT) {                                                                               \
+    case 2: rc = launch_gw_bc<DCV, 2>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 3: rc = launch_gw_bc<DCV, 3>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 4: rc = launch_gw_bc<DCV, 4>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 5: rc = launch_gw_bc<DCV, 5>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 6: rc = launch_gw_bc<DCV, 6>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 7: rc = launch_gw_bc<DCV, 7>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    case 8: rc = launch_gw_bc<DCV, 8>(a, net->bclass, grid, SW * QG * 64, lds, s); break;      \
+    default: rc = IRBFN_ERR_UNSUPPORTED;                                                      \
   }
+  if (net->DC == 7) { IRBFN_GW_NT(7) } else { IRBFN_GW_NT(8) }
+#undef IRBFN_GW_NT
   if (rc == IRBFN_OK) {
-    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16gram_wide<D=7,BC=%d,NT=%d,SW=%d,QG=%d>", net->bclass, NT, SW, QG);
+    snprintf(net->last_name, sizeof(net->last_name), "rbf_fwd_f16gram_wide<D=%d,BC=%d,NT=%d,SW=%d,QG=%d>", net->DC, net->bclass, NT, SW, QG);
     net->last_grid = grid;
     net->last_block = SW * QG * 64;
   }

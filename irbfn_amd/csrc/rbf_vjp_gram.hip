@@ -4,7 +4,7 @@
 //     u[q,k]    = alpha_k |x_q - c_k|^2 + beta                (the exactly-cancelling Gram expansion of K1g, rbf_forward_gram.hip:
 //                                                              rows = queries, cols = centres, k = slots -- the layout of hbar)
 //     dW[k,o]   = sum_q gamma_q phi[q,k] g[q,o]               (rows = outputs, cols = centres, k = 32 queries)         as K2h
-//     dC[k,i]   = sum_q tt[q,k] x'_qi,  stt[k] = sum_q tt[q,k] (rows = centres, cols = 7 coordinates + a column of ones, k = 32 queries)
+//     dC[k,i]   = sum_q tt[q,k] x'_qi,  stt[k] = sum_q tt[q,k] (rows = centres, cols = the coordinates + a column of ones, k = 32 queries)
 // with tt = hbar * gamma * dphi/dd2 and   d centers[k,i] = -2/sigma_k^2 (dC[k,i] - c'_ki stt[k]),
 //                                         d log_sigs[k]  = -2/sigma_k^2 sum_q tt[q,k] d2[q,k]   (d2 recovered from u per pair).
 // K2h (rbf_vjp_f16.hip) computes u and the centre gradients on the VALU: 15 + 7 of its ~30 instructions per (query, centre)
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* _
     gA2[s * 64 + lane] = mix;
   }
   // A operand of the dW MFMA (16x16x32): rows = outputs n, k = 8 g + j <-> query 16 (j >> 2) + 4 g + (j & 3), gamma_q g / s_g
-  // B operand of the dC MFMA (16x16x32): k as above, cols = coordinate n of x' / 2^ex (n < D), 1 (n = 7), 0
+  // B operand of the dC MFMA (16x16x32): k as above, cols = coordinate n of x' / 2^ex (n < D), 1 (n = 8), 0
   h8_t* gT = reinterpret_cast<h8_t*>(p + kVgDist + kVgGA);
   h8_t* xB = reinterpret_cast<h8_t*>(p + kVgDist + kVgGA + 2048);
   const float xinv = __builtin_ldexpf(1.0f, -hdr->ex);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* _
     const float gq = __shfl(gm, ql);
     float v = 0.0f, xv = 0.0f;
     if (q < B && n < O) v = gq * gout[q * O + n] / sg;
-    if (q < B) xv = n < D ? (x[q * D + n] - rn) * xinv : (n == 7 ? 1.0f : 0.0f);
+    if (q < B) xv = n < D ? (x[q * D + n] - rn) * xinv : (n == kGramDims ? 1.0f : 0.0f);
     _Float16 h, l;
     split_static_f16(v, h, l);
     th[j] = h; tl[j] = l;
@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
       const int o = 4 * g + r;
       if (o < a.OP && cid < a.Npad) dst[(size_t)(DC + 1 + o) * a.Npad + cid] = __builtin_fmaf(dWl[ct][r], kLoScale, dW[ct][r]) * wscale;
     }
-    // d centers: D rows = centres 4 g + r, column n = coordinate (n < DC) / the sum of tt (n = 7)
+    // d centers: D rows = centres 4 g + r, column n = coordinate (n < DC) / the sum of tt (n = 8)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float dv = __builtin_fmaf(dCl[ct][r], kLoScale, dC[ct][r]);
-      const float st = __shfl(dv, g * 16 + 7) * (1.0f / kWScale);       // sum of tts over the slice
+      const float st = __shfl(dv, g * 16 + kGramDims) * (1.0f / kWScale);   // sum of tts over the slice
       const int c2 = cb + ct * 16 + 4 * g + r;
       if (n < DC && c2 < a.Npad) {
         float out = 0.0f;
@@ -400,6 +400,7 @@ int launch_vjp_gram(irbfn_net* net, const float* x, const float* gout, int64_t B
     case 3: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<3>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
     case 4: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<4>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
     case 7: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<7>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
+    case 8: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<8>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
@@ -420,6 +421,7 @@ int launch_vjp_gram(irbfn_net* net, const float* x, const float* gout, int64_t B
     case 3: return launch_vjpg_dc<3>(a, net->bclass, grid, lds, s);
     case 4: return launch_vjpg_dc<4>(a, net->bclass, grid, lds, s);
     case 7: return launch_vjpg_dc<7>(a, net->bclass, grid, lds, s);
+    case 8: return launch_vjpg_dc<8>(a, net->bclass, grid, lds, s);
     default: return IRBFN_ERR_UNSUPPORTED;
   }
 }

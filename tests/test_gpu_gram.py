@@ -97,7 +97,8 @@ def test_gram_on_the_reference_s_trained_single_region_planner(gpu, B):
 
 @pytest.mark.parametrize("D,K,O,basis", [(3, 256, 5, "gaussian"), (4, 96, 16, "inverse_multiquadric"), (7, 200, 2, "inverse_quadratic"),
                                          (7, 33, 1, "gaussian_wide"), (5, 64, 7, "inverse_multiquadric"), (2, 50, 3, "gaussian_wider"),
-                                         (6, 1000, 10, "gaussian"), (7, 20, 4, "gaussian"), (4, 32, 16, "inverse_quadratic")])
+                                         (6, 1000, 10, "gaussian"), (7, 20, 4, "gaussian"), (4, 32, 16, "inverse_quadratic"),
+                                         (8, 300, 2, "gaussian"), (8, 100, 10, "inverse_multiquadric")])       # d = 8: the Frenet nets
 def test_gram_shapes_and_bases(gpu, D, K, O, basis):
     rng = np.random.default_rng(D * 100 + K)
     lo, hi = -np.ones(D) * 2, np.ones(D) * 3
@@ -310,6 +311,24 @@ def test_gram_wide_ill_conditioned_columns(gpu, O, case):
     assert rel.max() <= 1e-5, (case, O, rel.max())
 
 
+def test_gram_wide_d8_like_the_deeper_frenet_stage(gpu):
+    """d = 8, O = 64: the RBF stage + linear_pre1 of the reference's DeeperWCRBFNet Frenet planner (model.py:201-289) as one wide net."""
+    rng = np.random.default_rng(64)
+    D, K, O = 8, 300, 64
+    cfg = _card(D, K, O, "gaussian", [-1.0] * D, [2.0] * D)
+    params = {"params": {"rbf_list": {"centers": rng.uniform(-1.5, 2.5, size=(1, K, D)).astype(np.float32),
+                                      "log_sigs": rng.uniform(0.0, 1.0, size=(1, K)).astype(np.float32)},
+                         "linear": {"kernel": rng.normal(0, 0.3, size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    net = WCRBFNet.from_config(cfg)
+    x = rng.uniform(-1.0, 2.0, size=(2500, D)).astype(np.float32)
+    got = net.apply(params, x)
+    assert net.last_launch()["kernel"].startswith("rbf_fwd_f16gram_wide<D=8"), net.last_launch()
+    p64 = orc.cast_params(params, np.float64)
+    ref = orc.wcrbfnet_apply(cfg, p64, x.astype(np.float64))
+    scale = _terms_scale(cfg, p64, x.astype(np.float64)) + 1e-30
+    assert (np.abs(got - ref) / scale).max() <= 3e-6
+
+
 def test_gram_wide_queries_outside_the_box(gpu):
     cfg, params = configs.model_card(4), configs.synth_params(4)
     net = WCRBFNet.from_config(cfg)
@@ -363,6 +382,15 @@ def _vjp_case(case, rng):
         B = 2500
         x = rng.uniform(lo - 0.02, hi + 0.02, size=(B, 7)).astype(np.float32)
         g = rng.normal(size=(B, 10)).astype(np.float32)
+    elif case == "gauss_d8":
+        D, K, O = 8, 200, 2                                                  # the Frenet planners' width
+        cfg = _card(D, K, O, "gaussian", [-1.0] * D, [2.0] * D)
+        P = {"params": {"rbf_list": {"centers": rng.uniform(-1.5, 2.5, size=(1, K, D)).astype(np.float32),
+                                     "log_sigs": rng.uniform(0.0, 1.0, size=(1, K)).astype(np.float32)},
+                        "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+        B = 3000
+        x = rng.uniform(-1.1, 2.1, size=(B, D)).astype(np.float32)
+        g = rng.normal(size=(B, O)).astype(np.float32)
     else:
         D, K, O = 3, 96, 5
         cfg = _card(D, K, O, "inverse_multiquadric", [-2.0] * D, [3.0] * D)
@@ -377,7 +405,7 @@ def _vjp_case(case, rng):
     return cfg, P, x, g
 
 
-@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "gauss_ckpt", "imq_d3"])
+@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "gauss_ckpt", "imq_d3", "gauss_d8"])
 def test_vjp_gram_matches_valu_kernel_and_oracle(gpu, case):
     import torch
     cfg, P, x, g = _vjp_case(case, np.random.default_rng(11))
