@@ -331,7 +331,7 @@ bool gram_preferred(const irbfn_net* net, int64_t B) {
 
 // K1g for wide outputs (rbf_forward_gram_wide.hip): d = 7 or 8, the parameters fit the expansion
 bool gram_wide_preferred(const irbfn_net* net, int64_t B) {
-  return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && (net->DC == 7 || net->DC == 8) && B >= 2048;
+  return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && (net->DC == 7 || net->DC == 8) && B >= 2048 && net->N >= 256;
 }
 
 // S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (21 KiB of LDS per
