@@ -95,7 +95,7 @@ int irbfn_net_destroy(irbfn_net* net);
  * "linear": {"kernel"[K,O], "bias"[O]}} (checkpoint layout).  Device pointers; the
  * data is re-packed on `stream` into the descriptor's own record buffers (a few small kernels), so the
  * caller may overwrite its arrays afterwards.  Call again after every optimiser step.  For nets the
- * matrix-core kernel K1g can take (one region, O <= 16, d <= 7, fast basis) the call ends with ONE small
+ * matrix-core kernels K1g / K2g can take (one region, d <= 8, fast basis) the call ends with ONE small
  * synchronous read-back on `stream` (64 bytes: do the bound parameters fit K1g's expansion?) -- the
  * kernel choice of later forwards is a property of the parameters; every other net returns without
  * synchronising. */
@@ -131,13 +131,13 @@ typedef enum irbfn_option {
   IRBFN_OPT_COUNT = 15
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
-  IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; sparse multi-region gate: K1r; one region + fast basis: K1g (d <= 7, parameters inside its budget; O <= 16:
-                         B >= 12288; 16 < O <= 128: d = 7, B >= 2048) else K1h (O <= 128); O > 16: K1m; otherwise K1 */
+  IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; sparse multi-region gate: K1r; one region + fast basis: K1g (d <= 8, parameters inside its budget; O <= 16:
+                         B >= 12288; 16 < O <= 128: d = 7 or 8, B >= 2048, >= 256 centres) else K1h (O <= 128); O > 16: K1m; otherwise K1 */
   IRBFN_FWD_K1 = 1,   /* rbf_fwd_qlane: all-float32 VALU kernel (any net) */
   IRBFN_FWD_K1M = 2,  /* rbf_fwd_mfma: Phi x W on the f32-input matrix cores */
   IRBFN_FWD_K1H = 3,  /* rbf_fwd_f16mfma[_wide]: Phi x W on the f16 matrix cores, hi/lo operand pairs */
   IRBFN_FWD_K1R = 4,  /* rbf_fwd_sparse: several regions, every query visits only the regions whose gamma != 0 */
-  IRBFN_FWD_K1G = 5   /* rbf_fwd_f16gram[_wide]: one region, d <= 7 (O <= 16) / d = 7 (16 < O <= 128): the squared distances as an exactly-cancelling Gram expansion
+  IRBFN_FWD_K1G = 5   /* rbf_fwd_f16gram[_wide]: one region, d <= 8 (O <= 16) / d = 7 or 8 (16 < O <= 128): the squared distances as an exactly-cancelling Gram expansion
                          on the f16 matrix cores in front of K1h's Phi x W; IRBFN_ERR_UNSUPPORTED when the bound parameters
                          do not fit the expansion (widths of 1e-3 of the centres' spread, non-finite values) */
 } irbfn_fwd_kernel;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict_
 // ---- kernel ----------------------------------------------------------------------------------------------
 template <int DC, int BC, bool ROLL>
 __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl, int mode, unsigned char* lds) {
-  static_assert(DC <= kGramDims, "seven coordinate slots");
+  static_assert(DC <= kGramDims, "eight coordinate slots");
   const F16Args& a = ga.f;
   constexpr int CBL = f16_chunk_bytes(DC);                   // K1h's chunk image (the VALU path reads its records)
   constexpr int CB = kGramChunkBytes;
