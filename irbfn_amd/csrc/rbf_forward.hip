@@ -334,14 +334,14 @@ bool gram_wide_preferred(const irbfn_net* net, int64_t B) {
   return net->gram_img && net->gram_ok && net->O > 16 && net->O <= 128 && (net->DC == 7 || net->DC == 8) && B >= 2048 && net->N >= 256;
 }
 
-// S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (21 KiB of LDS per
-// slice).  Measured at the config-2 net (us; B = 16384 / 32768 / 65536 / 262144): S = 4, QG = 2: 36 / 71 / 135 / 529;
-// S = 2, QG = 4: 52 / 54 / 83 / 297; S = 1, QG = 8: 90 / 90 / 91 / 275 -- more slices while the launch is short of waves, never
-// more blocks than are resident at once.
+// S centre slices x QG query groups of 32 per block; the QG waves of a slice share one stream of chunk images (a ring of five,
+// 35 KiB of LDS per slice).  Measured at the config-2 net (profiles/r03_gram_batch_sweep.txt; us at B = 16384 / 24576 / 32768 /
+// 65536 / 131072 / 262144): S = 4, QG = 2: 38 / 70 / 72 / 139 / 275 / 547; S = 2, QG = 4: 53 / 53 / 55 / 82 / 155 / 298; S = 1, QG = 8:
+// 88 / 88 / 88 / 88 / 142 / 273 -- more slices while the launch is short of waves, never more blocks than are resident at once.
 void gram_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_out) {
   const long groups = (B + 31) / 32;
   const int nchunks = (net->N + 31) / 32;
-  int S = groups <= 768 ? 4 : (groups <= 3072 ? 2 : 1);
+  int S = groups <= 512 ? 4 : (groups <= 3072 ? 2 : 1);
   while (S > 1 && nchunks / (2 * S) < 4) S /= 2;            // at least 8 chunks per wave
   S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
   if (S > 7 || S > nchunks) S = 1;
