@@ -23,6 +23,7 @@ _SLP = ["-fno-slp-vectorize"] if os.environ.get("IRBFN_NO_SLP") == "1" else []
 # (source, object name, extra flags)
 UNITS = [
     ("abi.hip", "abi.o", []),
+    ("pack_all.hip", "pack_all.o", []),          # K0: every image of a net in two launches
     ("rbf_forward.hip", "rbf_forward.o", []),
     # NOTE on -fno-slp-vectorize (IRBFN_NO_SLP=1): hipcc's SLP vectoriser fuses the weight-row FMAs
     # into v_pk_fma_f32 with an SGPR-pair operand; measured on MI355X (cfg-2) the packed form is

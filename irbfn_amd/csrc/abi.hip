@@ -90,6 +90,9 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
   if (gram_eligible(net)) {
     alloc((void**)&net->gram_img, gram_image_bytes(net));
     alloc((void**)&net->gram_hdr, gram_header_bytes());
+    alloc((void**)&net->pack_part, pack_partials_bytes(net));
+    alloc((void**)&net->vjp_flags, 64 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(net->vjp_flags, 0, 64 * sizeof(int));
   }
   alloc((void**)&net->small_part, small_workspace_floats(OP) * sizeof(float));
   alloc((void**)&net->small_ticket, small_ticket_count() * sizeof(unsigned int));
@@ -125,7 +128,7 @@ int irbfn_net_create(irbfn_net** out_net, int D, int R, int K, int O, int basis,
 
 int irbfn_net_destroy(irbfn_net* net) {
   if (!net) return IRBFN_OK;
-  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->gram_img, net->gram_hdr, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
+  void* bufs[] = {net->rec, net->bias, net->sig2, net->recm, net->f16_img, net->f16_oscale, net->gram_img, net->gram_hdr, net->pack_part, net->vjp_flags, net->small_part, net->small_ticket, net->gate_lo, net->gate_hi, net->gate_delta, net->gate_ranges};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   sparse_free(net);
@@ -136,10 +139,7 @@ int irbfn_net_destroy(irbfn_net* net) {
 int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* log_sigs_dev,
                          const float* kernel_dev, const float* bias_dev, void* stream) {
   if (!net || !centers_dev || !log_sigs_dev || !kernel_dev || !bias_dev) return IRBFN_ERR_BAD_ARG;
-  int rc = launch_pack(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
-  if (rc == IRBFN_OK && net->recm) rc = launch_pack_mfma(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
-  if (rc == IRBFN_OK && net->f16_img) rc = launch_pack_f16(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
-  if (rc == IRBFN_OK && net->gram_img) rc = launch_pack_gram(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
+  int rc = launch_pack_all(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
   if (rc == IRBFN_OK && net->sp_ok) rc = launch_pack_sparse(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;

@@ -56,6 +56,8 @@ struct GateTables {        // device pointers owned by the descriptor
   int nsplit, max_ranges, n_ranges;
 };
 
+__host__ __device__ constexpr int mfma_cw(int D) { return (D + 1 + 3) & ~3; }   // K1m record: c[D], scale, pad
+
 struct DynParams {         // dynamics.py:24-36
   float p[13];
 };
@@ -81,6 +83,9 @@ struct irbfn_net {
   int gram_ok;              // K1g: the parameters fit the expansion's exactness budget (read back by set_params)
   int gram_exp[5];          // K1g: exponents ex, ec, eq, ea, e2 (diagnostics)
   int gram_checked;         // K1g: gram_ok has been read back at least once (IRBFN_OPT_GRAM_STICKY)
+  float* pack_part;         // K1g: partial statistics of the pack, one row per 1024 centres (pack_all.hip)
+  int* vjp_flags;           // K2g: ring of 64 hand-over words (rbf_vjp.hip); zero at creation, never reset
+  int vjp_gen;              // K2g: generation number of the last VJP call
   float* small_part;            // K1s workspace part[NB][B][OP] (small-batch latency kernel)
   unsigned int* small_ticket;   // K1s arrival counters [64], zero between launches
   // raw parameter pointers are NOT kept: set_params copies what it needs
@@ -106,20 +111,19 @@ struct irbfn_net {
 
 namespace irbfn {
 // launchers implemented per translation unit
-int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
-                const float* bias, hipStream_t s);
+// K0 (pack_all.hip): every image of the net in two launches
+int launch_pack_all(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, const float* bias,
+                    hipStream_t s);
+size_t pack_partials_bytes(const irbfn_net* net);
 int launch_forward(irbfn_net* net, const float* x, float* out, int64_t B, hipStream_t s);
 int launch_forward_gamma(irbfn_net* net, const float* x, const float* gamma, float* out, int64_t B, hipStream_t s);
 int launch_cluster_gate(const float* x, const float* wc, const float* bc, float* logits, float* gamma, int64_t B, int D,
                         int R, hipStream_t s);
 bool mfma_eligible(const irbfn_net* net);
 size_t mfma_record_floats(int D, int O);
-int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
-                     hipStream_t s);
 int launch_forward_mfma(irbfn_net* net, const float* x, float* out, int64_t B, int QJ, int nw, hipStream_t s);
 bool f16_eligible(const irbfn_net* net);
 size_t f16_image_bytes(const irbfn_net* net);
-int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
 int launch_forward_f16(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, int terms, hipStream_t s);
 bool gram_eligible(const irbfn_net* net);
 bool gram_preferred(const irbfn_net* net, int64_t B);
@@ -127,7 +131,6 @@ bool gram_wide_preferred(const irbfn_net* net, int64_t B);
 void gram_geometry(const irbfn_net* net, int64_t B, int* S, int* QG);
 size_t gram_image_bytes(const irbfn_net* net);
 size_t gram_header_bytes();
-int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
 int launch_forward_gram(irbfn_net* net, const float* x, float* out, int64_t B, int S, int QG, hipStream_t s);
 int launch_tick_gram_narrow(irbfn_net* net, int mode, const float* x, const int* mirror, const float* state0, const DynParams& dp,
                             float* controls, float* states, int64_t B, int T, hipStream_t s);

@@ -31,41 +31,6 @@ int padded_D(int D) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K0: pack the parameter pytree into per-centre records  rec[n] = { c[0..DC), scale, W[k][0..OP) }.
-// n = r*K + k; the weight row is replicated per region so that the hot loop reads ONE contiguous
-// scalar stream.  Runs once per irbfn_net_set_params (N*S floats, 0.33 MB at cfg-2).
-// ------------------------------------------------------------------------------------------------
-__global__ void pack_records_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                    const float* __restrict__ kernel, const float* __restrict__ bias,
-                                    float* __restrict__ rec, float* __restrict__ bias_out,
-                                    float* __restrict__ sig2, int N, int K, int D, int DC, int O, int OP,
-                                    int S, int bclass, float gscale) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < OP) bias_out[n] = n < O ? bias[n] : 0.0f;
-  if (n >= N) return;
-  const int k = n % K;
-  float* r = rec + (size_t)n * S;
-  for (int j = 0; j < DC; ++j) r[j] = j < D ? centers[(size_t)n * D + j] : 0.0f;
-  const float s2 = expf(-2.0f * log_sigs[n]);          // 1/sigma^2, sigma = exp(log_sig) (flax_rbf.py:280)
-  sig2[n] = s2;
-  r[DC] = bclass == BC_GAUSS ? -gscale * 1.4426950408889634f * s2 : s2;
-  for (int o = 0; o < OP; ++o) r[DC + 1 + o] = o < O ? kernel[(size_t)k * O + o] : 0.0f;
-  for (int j = DC + 1 + OP; j < S; ++j) r[j] = 0.0f;
-}
-
-int launch_pack(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
-                const float* bias, hipStream_t s) {
-  const int n = net->N > net->OP ? net->N : net->OP;
-  const int block = 256;
-  const int grid = (n + block - 1) / block;
-  hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(block), 0, s, centers, log_sigs, kernel, bias,
-                     net->rec, net->bias, net->sig2, net->N, net->K, net->D, net->DC, net->O, net->OP,
-                     net->S, net->bclass, gauss_scale(net->basis));
-  IRBFN_HIP_CHECK(hipGetLastError());
-  return IRBFN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // gate kernel: _region_activation (model.py:42-95) -> gamma[B][R].  One wave per 64 queries; the
 // per-dimension factors are tabulated in LDS once, then every region is a product of nsplit
 // look-ups.  Used by irbfn_net_gate and as the pre-pass of the VJP.

@@ -42,71 +42,6 @@
 
 namespace irbfn {
 
-// ---- pack ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void f16_colscale_kernel(const float* __restrict__ kernel, float* __restrict__ oscale,
-                                                           int K, int O) {
-  __shared__ float red[256];
-  const int o = blockIdx.x;
-  float m = 0.0f;
-  if (o < O)
-    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(kernel[(size_t)k * O + o]));
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    float s = 1.0f;
-    const float mx = red[0];
-    if (mx > 0.0f && mx < 3.0e38f) {             // zero column / Inf / NaN: unscaled
-      int e;
-      (void)frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)  ->  2^e > mx
-      s = ldexpf(1.0f, e);
-    }
-    oscale[o] = s;
-  }
-}
-
-// one thread per (chunk, centre-in-chunk): record + this centre's 16 weights of both parts
-__global__ __launch_bounds__(256) void f16_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                                       const float* __restrict__ kernel, const float* __restrict__ oscale,
-                                                       unsigned char* __restrict__ img, int N, int K, int D, int RF,
-                                                       int O, int NT, int bclass, float gscale, int nchunks) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nchunks * kF16Chunk) return;
-  const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
-  const int n = idx;                                         // centre index (R == 1: n == k)
-  const size_t cb = (size_t)kF16Chunk * RF * 4 + (size_t)NT * 2 * kF16WBytes + (NT == 1 ? kF16WBytes : 0);
-  unsigned char* p = img + (size_t)c * cb;
-  float* rec = reinterpret_cast<float*>(p) + kk * RF;
-  const bool real = n < N;
-  for (int j = 0; j < RF - 1; ++j) rec[j] = (real && j < D) ? centers[(size_t)n * D + j] : 0.0f;
-  float sc = 0.0f;                                           // padding centre: P = 2^kPhiExp exactly, W = 0
-  if (real) {
-    const float s2 = expf(-2.0f * log_sigs[n]);              // 1/sigma^2 (flax_rbf.py:280)
-    if (bclass == BC_GAUSS) sc = -gscale * 1.4426950408889634f * s2;   // P = 2^(r2*sc + kPhiExp)
-    else if (bclass == BC_IQ) sc = s2 * kPhiInv;                       // P = 1 / (2^-kPhiExp (1 + d2))
-    else sc = s2 * kPhiInv * kPhiInv;                                  // P = rsqrt(2^-2kPhiExp (1 + d2))
-  }
-  rec[RF - 1] = sc;
-  const int g = kk >> 3, j = kk & 7;
-  for (int ct = 0; ct < NT; ++ct) {
-    _Float16* wh = reinterpret_cast<_Float16*>(p + (size_t)kF16Chunk * RF * 4 + (size_t)ct * 2 * kF16WBytes);
-    _Float16* wl = wh + kF16WBytes / 2;
-    for (int oo = 0; oo < 16; ++oo) {
-      const int o = ct * 16 + oo;
-      float w = 0.0f;                                        // W / s_o, |.| < 1 (exact scaling)
-      if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
-      _Float16 h, l;
-      split_static_f16(w, h, l);
-      wh[(g * 16 + oo) * 8 + j] = h;
-      wl[(g * 16 + oo) * 8 + j] = l;
-      if (NT == 1) reinterpret_cast<__bf16*>(wl + kF16WBytes / 2)[(g * 16 + oo) * 8 + j] = (__bf16)(w * kWScale);
-    }
-  }
-}
-
 // TERMS: 3 = (hi, lo) f16 pairs (the product path); 1 = plain f16 operands; BF (with TERMS = 1) = plain bf16 operands --
 // the two reduced-precision variants BASELINE config 5 asks to report, reachable only through an explicit option.
 // ROLL (rbf_tick_f16mfma, the planning tick of the narrow nets: irbfn_planner.py:203-212): the slice-0 wave of a query
@@ -452,19 +387,6 @@ static int f16_nt(const irbfn_net* net) { return (net->O + 15) / 16; }
 size_t f16_image_bytes(const irbfn_net* net) {
   const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
   return (size_t)nchunks * f16_chunk_bytes(net->DC, f16_nt(net));
-}
-
-int launch_pack_f16(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
-  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
-  const int NT = f16_nt(net);
-  hipLaunchKernelGGL(f16_colscale_kernel, dim3(16 * NT), dim3(256), 0, s, kernel, net->f16_oscale, net->K, net->O);
-  IRBFN_HIP_CHECK(hipGetLastError());
-  const int total = nchunks * kF16Chunk;
-  hipLaunchKernelGGL(f16_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, centers, log_sigs, kernel,
-                     net->f16_oscale, net->f16_img, net->N, net->K, net->D, f16_rf(net->DC), net->O, NT, net->bclass,
-                     gauss_scale(net->basis), nchunks);
-  IRBFN_HIP_CHECK(hipGetLastError());
-  return IRBFN_OK;
 }
 
 template <int DC, int NT>

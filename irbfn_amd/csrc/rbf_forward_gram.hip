@@ -39,226 +39,6 @@
 
 namespace irbfn {
 
-// ---- pack ------------------------------------------------------------------------------------------------
-template <int BC>
-__device__ inline void gram_alpha_beta(double s2, double gscale, double& alpha, double& beta) {
-  if (BC == BC_GAUSS) { alpha = -gscale * 1.4426950408889634 * s2; beta = (double)kPhiExp; }     // P = 2^(alpha d2 + 14)
-  else if (BC == BC_IQ) { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                // P = 1 / (2^-14 (1 + d2 s2))
-  else { alpha = s2 * (double)kPhiInv; beta = (double)kPhiInv; }                                 // P = rsqrt(2^-14 (1 + d2 s2)) = 2^7 phi
-}
-__device__ inline double gram_pow2(int e) {                  // 2^e, -1022 <= e <= 1023, without the library's ldexp
-  return __builtin_bit_cast(double, (unsigned long long)(1023 + e) << 52);
-}
-__device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e
-  if (!(v > 0.0)) return -40;
-  int e;
-  (void)frexp(v, &e);                                        // v = f 2^e, f in [0.5, 1)
-  return e;
-}
-
-// one block: origin, exponents, the exactness budget
-__global__ __launch_bounds__(1024) void gram_stats_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                                          GramHdr* __restrict__ hdr, int N, int D, int bclass,
-                                                          float gscale) {
-  __shared__ float red[16][16];                              // [wave][value]
-  __shared__ float r_sh[8];
-  __shared__ float tot[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // max of NV values per thread over the block: wave shuffles, one LDS pass, results in tot[]
-  auto block_max_n = [&](float (&v)[16], int NV) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (i < NV) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v[i] = fmaxf(v[i], __shfl_xor(v[i], off));
-      }
-    if (lane == 0)
-      for (int i = 0; i < NV; ++i) red[wave][i] = v[i];
-    __syncthreads();
-    if (tid < NV) {
-      float m = red[0][tid];
-      for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w][tid]);
-      tot[tid] = m;
-    }
-    __syncthreads();
-  };
-  // ONE pass: per coordinate max and -min of the centres (origin = midpoint, half widths), the largest |alpha|, finiteness.  The
-  // bounds on C = -2 alpha c' and on c2 = alpha |c'|^2 + beta are products of these maxima (at most the true maxima x the spread
-  // of alpha over the centres: a coarser grid where it matters, never a wrong one) -- a second pass over the centres with the
-  // origin known would make them tight at twice the kernel time, and this kernel runs at every irbfn_net_set_params.
-  bool finite = true;
-  float mm[16];                                              // [0, 8): max_i, [8, 16): -min_i
-  for (int i = 0; i < 16; ++i) mm[i] = -3.0e38f;
-  float am = 0.0f;
-  for (int k = tid; k < N; k += 1024) {
-    for (int i = 0; i < D && i < 8; ++i) {
-      const float c = centers[(size_t)k * D + i];
-      finite = finite && (fabsf(c) < 3.0e38f);
-      mm[i] = fmaxf(mm[i], c);
-      mm[8 + i] = fmaxf(mm[8 + i], -c);
-    }
-    const double s2 = (double)expf(-2.0f * log_sigs[k]);     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280)
-    double alpha, beta;
-    if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(s2, gscale, alpha, beta);
-    else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(s2, gscale, alpha, beta);
-    else gram_alpha_beta<BC_IMQ>(s2, gscale, alpha, beta);
-    const float fa1 = (float)fabs(alpha);
-    finite = finite && (fa1 < 1.0e30f);
-    am = fmaxf(am, fa1);
-  }
-  block_max_n(mm, 16);
-  float hw2 = 0.0f, hwm = 0.0f;                              // sum of the squared half widths, largest half width
-  if (tid == 0) {
-    for (int i = 0; i < 8; ++i) {
-      r_sh[i] = i < D ? 0.5f * tot[i] - 0.5f * tot[8 + i] : 0.0f;
-      const float hw = i < D ? fmaxf(tot[i] - r_sh[i], r_sh[i] + tot[8 + i]) * 1.0000005f : 0.0f;     // the rounded midpoint's two sides
-      hw2 += hw * hw;
-      hwm = fmaxf(hwm, hw);
-    }
-  }
-  float st[16];
-  for (int i = 0; i < 16; ++i) st[i] = 0.0f;
-  st[0] = am; st[1] = finite ? 0.0f : 1.0f;
-  block_max_n(st, 2);
-  double beta0, alpha0;
-  if (bclass == BC_GAUSS) gram_alpha_beta<BC_GAUSS>(1.0, gscale, alpha0, beta0);
-  else if (bclass == BC_IQ) gram_alpha_beta<BC_IQ>(1.0, gscale, alpha0, beta0);
-  else gram_alpha_beta<BC_IMQ>(1.0, gscale, alpha0, beta0);
-  const float fc = hwm, fa = tot[0], fC = 2.0f * tot[0] * hwm, f2 = tot[0] * hw2 + (float)fabs(beta0), bad = tot[1];
-  if (tid == 0) {
-    GramHdr h;
-    for (int i = 0; i < 8; ++i) h.r[i] = r_sh[i];
-    // the box of representable queries: the centres' box with a quarter to spare (queries beyond it take the VALU distances;
-    // the card's own bounds are NOT added: a wide gate around a compact set of centres would coarsen every head)
-    const double xm = fc;
-    h.ex = gram_exp_above(1.25 * xm * 1.0000002);
-    h.ea = gram_exp_above(fa * 1.0000002);
-    h.ec = gram_exp_above(fC * 1.0000002);
-    int dbits = 0;
-    while ((1 << dbits) < D) ++dbits;
-    h.cabs = fc; h.amax = fa; h.cmax = fC; h.c2max = f2;
-    // exactness budget of the head sum: the sum of the magnitudes of its terms -- a bound on every partial sum of the adder
-    // tree -- stays below 2^24 grid units, grid = 2^(ex + ec - 20).  |x'_i| < 2^ex is what the kernel lets through.  A coarser
-    // grid (ec + 1: heads of C one bit shorter, its tails one bit larger) buys a factor of two.
-    const double xb = ldexp(1.0, h.ex);
-    const double worst = ((double)fa * D * xb * xb + (double)D * fC * xb + (double)f2) * (1.0 + 1.0 / 256.0);
-    while (worst >= ldexp(1.0, h.ex + h.ec + 4) && h.ec < 40) ++h.ec;
-    h.eq = 2 * h.ex + dbits;
-    if (h.eq + h.ea < h.ex + h.ec) h.eq = h.ex + h.ec - h.ea;                 // Q x alpha heads on the cross grid
-    h.e2 = gram_exp_above(f2 * 1.0000002);
-    if (h.e2 < h.ex + h.ec + 1) h.e2 = h.ex + h.ec + 1;                        // second c2 head on the cross grid
-    bool ok = bad == 0.0f && fc > 0.0f && fa > 0.0f;
-    // truncation in the two tail MFMAs: at most 2^-24 of D tail products of 2^(ex + ec - 10) each -- kept below 2^-20 in u
-    ok = ok && h.ex + h.ec + dbits <= 14;
-    // f16 range of every operand: |operand| <= 2^ax resp. 2^(T - ax), heads need ax - 10 >= -24
-    const int Ts[3] = {h.ex + h.ec, h.eq + h.ea, h.e2};
-    for (int t = 0; t < 3; ++t) ok = ok && gram_ax(Ts[t]) <= 14 && Ts[t] - gram_ax(Ts[t]) <= 14 && Ts[t] >= -20;
-    ok = ok && h.ex <= 12 && h.ex >= -12;
-    h.ok = ok ? 1 : 0;
-    *hdr = h;
-  }
-}
-
-// v (|v| < 2^E) -> n0 (fixed point, grid 2^-10), n1, n2 (f16 values), v = 2^E (n0 + 2^-11 n1 + 2^-22 n2)
-__device__ inline void gram_parts_d(double v, int E, double (&n)[3]) {
-  const double a = v * gram_pow2(-E);
-  n[0] = __builtin_rint(a * 1024.0) * (1.0 / 1024.0);
-  const double r1 = (a - n[0]) * 2048.0;
-  n[1] = (double)(_Float16)(float)r1;
-  const double r2 = (r1 - n[1]) * 2048.0;
-  n[2] = (double)(_Float16)(float)r2;
-}
-// c2: two fixed-point heads, two float tails
-__device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
-  const double a = v * gram_pow2(-E);
-  n[0] = __builtin_rint(a * 1024.0) * (1.0 / 1024.0);
-  const double r1 = (a - n[0]) * 2048.0;
-  n[1] = __builtin_rint(r1 * 1024.0) * (1.0 / 1024.0);
-  const double r2 = (r1 - n[1]) * 2048.0;
-  n[2] = (double)(_Float16)(float)r2;
-  const double r3 = (r2 - n[2]) * 2048.0;
-  n[3] = (double)(_Float16)(float)r3;
-}
-
-// sixteen threads per (chunk, centre-in-chunk): thread `part` < 8 writes the slots of coordinate `part` (1 head, 5 tails), thread 8
-// the slots of Q x alpha and of c2 (3 heads, 7 tails) and the empty ones; every thread the W values of output `part` of every
-// column tile
-constexpr int kGramPackThreads = 16;
-static_assert(kGramDims + 1 <= kGramPackThreads && kGramDims + 3 <= 16 && 5 * kGramDims + 7 <= 64, "slots of the expansion");
-template <int BC>
-__global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                                        const float* __restrict__ kernel, const float* __restrict__ oscale,
-                                                        const GramHdr* __restrict__ hdr, unsigned char* __restrict__ img, int N,
-                                                        int K, int D, int O, int NT, float gscale, int nchunks) {
-  const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-  const int idx = tix / kGramPackThreads, part = tix % kGramPackThreads;
-  if (idx >= nchunks * kF16Chunk) return;
-  const int c = idx / kF16Chunk, kk = idx % kF16Chunk;
-  const int n = idx;
-  const bool real = n < N;
-  const GramHdr h = *hdr;
-  unsigned char* p = img + (size_t)c * gram_chunk_bytes(NT);
-  const int ct = kk >> 4, row = kk & 15;                     // centre tile, A-operand row
-  _Float16* head = reinterpret_cast<_Float16*>(p + ct * 512);                  // lane (g, row): k = 4 g + j
-  auto put_head = [&](int s, double v, int T) { head[((s >> 2) * 16 + row) * 4 + (s & 3)] = (_Float16)(float)(v * gram_pow2(T - gram_ax(T))); };
-  auto put_tail = [&](int s, double v, int T) {
-    const int half = s >> 5, g = (s >> 3) & 3, j = s & 7;
-    _Float16* tail = reinterpret_cast<_Float16*>(p + kGramHeadBytes + (ct * 2 + half) * 1024);
-    tail[(g * 16 + row) * 8 + j] = (_Float16)(float)(v * gram_pow2(T - gram_ax(T)));
-  };
-  double alpha = 0.0, beta = 0.0;
-  if (h.ok) {
-    const double s2 = real ? (double)expf(-2.0f * log_sigs[n]) : 1.0;     // 1/sigma^2 as K1 / K1h have it (float32, flax_rbf.py:280); every
-    gram_alpha_beta<BC>(s2, gscale, alpha, beta);                          // term of the expansion uses this one value
-    if (!real) alpha = 0.0;                                  // a padding centre: u = beta (P finite), its W rows are 0
-  }
-  if (part < kGramDims) {
-    double nC[3] = {0.0, 0.0, 0.0};
-    if (real && h.ok && part < D) gram_parts_d(-2.0 * alpha * ((double)centers[(size_t)n * D + part] - (double)h.r[part]), h.ec, nC);
-    put_head(part, nC[0], h.ex + h.ec);
-    for (int m = 0; m < 5; ++m) {
-      const int q = gram_comb_q(m);
-      put_tail(5 * part + m, nC[q], h.ex + h.ec - 11 * (gram_comb_p(m) + q));
-    }
-  } else if (part == kGramDims) {
-    double nA[3] = {0.0, 0.0, 0.0}, n2[4] = {0.0, 0.0, 0.0, 0.0};
-    if (h.ok) {
-      double c2 = beta;
-      if (real)
-        for (int i = 0; i < D && i < kGramDims; ++i) {
-          const double cp = (double)centers[(size_t)n * D + i] - (double)h.r[i];
-          c2 += alpha * cp * cp;
-        }
-      gram_parts_d(alpha, h.ea, nA);
-      gram_parts_c2(c2, h.e2, n2);
-    }
-    put_head(kGramDims, nA[0], h.eq + h.ea);
-    put_head(kGramDims + 1, n2[0], h.e2);
-    put_head(kGramDims + 2, n2[1], h.e2 - 11);
-    for (int s = kGramDims + 3; s < 16; ++s) put_head(s, 0.0, 0);
-    for (int m = 0; m < 5; ++m) {
-      const int q = gram_comb_q(m);
-      put_tail(5 * kGramDims + m, nA[q], h.eq + h.ea - 11 * (gram_comb_p(m) + q));
-    }
-    put_tail(5 * kGramDims + 5, n2[2], h.e2 - 22);
-    put_tail(5 * kGramDims + 6, n2[3], h.e2 - 33);
-    for (int s = 5 * kGramDims + 7; s < 64; ++s) put_tail(s, 0.0, 0);
-  }
-  // W rows in the k order of the Phi x W product: centre 16 ct + 4 g + r <-> k = 8 g + 4 ct + r
-  const int g = row >> 2, j = ct * 4 + (row & 3);
-  for (int wt = 0; wt < NT; ++wt) {                          // column tiles of 16 outputs: W hi, W lo
-    _Float16* wh = reinterpret_cast<_Float16*>(p + kGramOpBytes + (size_t)wt * 2 * kF16WBytes);
-    _Float16* wl = wh + kF16WBytes / 2;
-    const int oo = part, o = wt * 16 + oo;
-    float w = 0.0f;
-    if (real && o < O) w = kernel[(size_t)(n % K) * O + o] / oscale[o];
-    _Float16 hh, ll;
-    split_static_f16(w, hh, ll);
-    wh[(g * 16 + oo) * 8 + j] = hh;
-    wl[(g * 16 + oo) * 8 + j] = ll;
-  }
-}
-
 // ---- kernel ----------------------------------------------------------------------------------------------
 template <int DC, int BC, bool ROLL>
 __device__ __forceinline__ void gram_body(const GramArgs& ga, const F16Roll& rl, int mode, unsigned char* lds) {
@@ -445,34 +225,6 @@ size_t gram_image_bytes(const irbfn_net* net) {
 }
 
 size_t gram_header_bytes() { return sizeof(GramHdr); }
-
-// after K1h's pack (needs its column scales).  Reads the header back (one small synchronous copy): whether this net
-// runs on K1g is a property of its parameters.
-int launch_pack_gram(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
-  const int nchunks = (net->N + kF16Chunk - 1) / kF16Chunk;
-  GramHdr* hdr = reinterpret_cast<GramHdr*>(net->gram_hdr);
-  hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(1024), 0, s, centers, log_sigs, hdr, net->N, net->D,
-                     net->bclass, gauss_scale(net->basis));
-  IRBFN_HIP_CHECK(hipGetLastError());
-  const int total = nchunks * kF16Chunk * kGramPackThreads;
-  const dim3 grid((total + 255) / 256), block(256);
-  const float gs = gauss_scale(net->basis);
-  switch (net->bclass) {
-    case BC_GAUSS: hipLaunchKernelGGL((gram_pack_kernel<BC_GAUSS>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
-    case BC_IQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
-    case BC_IMQ: hipLaunchKernelGGL((gram_pack_kernel<BC_IMQ>), grid, block, 0, s, centers, log_sigs, kernel, net->f16_oscale, hdr, net->gram_img, net->N, net->K, net->D, net->O, gram_nt(net), gs, nchunks); break;
-    default: return IRBFN_ERR_UNSUPPORTED;
-  }
-  IRBFN_HIP_CHECK(hipGetLastError());
-  if (net->opt[IRBFN_OPT_GRAM_STICKY] != 0 && net->gram_checked) return IRBFN_OK;     // the first verdict stands (training loops)
-  GramHdr h;
-  IRBFN_HIP_CHECK(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, s));
-  IRBFN_HIP_CHECK(hipStreamSynchronize(s));
-  net->gram_checked = 1;
-  net->gram_ok = h.ok;
-  net->gram_exp[0] = h.ex; net->gram_exp[1] = h.ec; net->gram_exp[2] = h.eq; net->gram_exp[3] = h.ea; net->gram_exp[4] = h.e2;
-  return IRBFN_OK;
-}
 
 #ifdef IRBFN_GRAM_STAMPS
 extern "C" int irbfn_debug_gram_stamps(unsigned long long* out32) {

@@ -25,27 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChunk = 16;     // centres per LDS chunk (4 MFMA k-steps)
 
-__host__ __device__ constexpr int mfma_cw(int D) { return (D + 1 + 3) & ~3; }   // c[D], scale, pad
-
-// pack: recm[n] = { c[0..D), scale at [CW-1]... } -- layout: c at [0..D), scale at [D], zeros to CW,
-// then W[k][0..16*NT) zero padded.  Centres n >= N (padding to a multiple of kChunk) have W = 0.
-__global__ void pack_mfma_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                 const float* __restrict__ kernel, float* __restrict__ recm, int N, int Npad,
-                                 int K, int D, int CW, int O, int OW, int bclass, float gscale) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= Npad) return;
-  float* r = recm + (size_t)n * (CW + OW);
-  if (n >= N) {
-    for (int j = 0; j < CW + OW; ++j) r[j] = 0.0f;
-    return;
-  }
-  const int k = n % K;
-  for (int j = 0; j < CW; ++j) r[j] = j < D ? centers[(size_t)n * D + j] : 0.0f;
-  const float s2 = expf(-2.0f * log_sigs[n]);
-  r[D] = bclass == BC_GAUSS ? -gscale * 1.4426950408889634f * s2 : s2;
-  for (int o = 0; o < OW; ++o) r[CW + o] = o < O ? kernel[(size_t)k * O + o] : 0.0f;
-}
-
 struct MfmaArgs {
   const float* __restrict__ x;      // [B][D]
   const float* __restrict__ recm;   // [Npad][RS]
@@ -207,15 +186,6 @@ bool mfma_eligible(const irbfn_net* net) {
   return net->R == 1 && net->bclass != BC_GENERIC && net->D >= 2 && net->D <= 8 && net->O <= 128;
 }
 
-int launch_pack_mfma(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel,
-                     hipStream_t s) {
-  const int CW = mfma_cw(net->D), OW = 16 * ((net->O + 15) / 16);
-  const int block = 256, grid = (net->Npad + block - 1) / block;
-  hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(block), 0, s, centers, log_sigs, kernel, net->recm, net->N,
-                     net->Npad, net->K, net->D, CW, net->O, OW, net->bclass, gauss_scale(net->basis));
-  IRBFN_HIP_CHECK(hipGetLastError());
-  return IRBFN_OK;
-}
 
 template <int D, int NT, int QJ>
 static int launch_mfma_bc(const MfmaArgs& a, int bc, int nw, size_t lds, long tiles, hipStream_t s) {

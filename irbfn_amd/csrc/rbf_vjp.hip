@@ -234,13 +234,31 @@ __global__ __launch_bounds__(256) void rbf_vjp_kernel(const VjpArgs a) {
 // sum over the regions of the per-centre values, one wave per output, fixed tree.  (Round 1 summed R x QSB terms per
 // output value in ONE thread: 100 threads x 128 regions x 24 slices of dependent loads = 2.2 ms of the 2.6 ms training
 // step of the reference's 128-region net at its batch size of 80000.)
+// Row V of the grid (blockIdx.y == V) is the second stage of the bias gradient: block o sums the per-block column sums of g
+// (colsum_partial_kernel) -- a launch of its own until round 3.
 __global__ __launch_bounds__(256) void vjp_reduce_kernel(float* __restrict__ part, float* __restrict__ g_centers,
                                                          float* __restrict__ g_log_sigs, float* __restrict__ g_kernel, int QSB,
-                                                         int V, int Npad, int N, int K, int R, int D, int DC, int O) {
+                                                         int V, int Npad, int N, int K, int R, int D, int DC, int O,
+                                                         const float* __restrict__ bpart, float* __restrict__ g_bias, int bias_blocks) {
   // block = (value v, 64 consecutive centres) x 4 slice groups: thread (sg, l) sums slices sg, sg + 4, ... in order, the
   // four partial sums are added in a fixed order (small nets have few centre groups and hundreds of slices)
   __shared__ float sm[4][kWave];
   const int l = threadIdx.x & (kWave - 1), sg = threadIdx.x >> 6;
+  if (blockIdx.y == (unsigned)V) {
+    const int o = blockIdx.x, t = threadIdx.x;
+    if (o >= O || bpart == nullptr) return;
+    float* sb = &sm[0][0];
+    float sacc = 0.0f;
+    for (int b = t; b < bias_blocks; b += 256) sacc += bpart[(size_t)b * O + o];
+    sb[t] = sacc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {             // fixed tree -> deterministic
+      if (t < w) sb[t] += sb[t + w];
+      __syncthreads();
+    }
+    if (t == 0) g_bias[o] = sb[0];
+    return;
+  }
   const int v = blockIdx.y, n = blockIdx.x * kWave + l;
   if ((v >= D && v < DC) || v > DC + O) return;            // padded coordinate / output slots (whole block)
   float s = 0.0f;
@@ -267,9 +285,11 @@ __global__ __launch_bounds__(64) void vjp_reduce_regions_kernel(const float* __r
 }
 
 int launch_vjp_reduce(const irbfn_net* net, float* part, float* g_centers, float* g_log_sigs, float* g_kernel, int QSB, int V,
-                      int Npad, hipStream_t s) {
-  hipLaunchKernelGGL(vjp_reduce_kernel, dim3((unsigned)((net->N + kWave - 1) / kWave), V), dim3(256), 0, s, part, g_centers,
-                     g_log_sigs, g_kernel, QSB, V, Npad, net->N, net->K, net->R, net->D, net->DC, net->O);
+                      int Npad, hipStream_t s, const float* bpart, float* g_bias, int bias_blocks) {
+  unsigned gx = (unsigned)((net->N + kWave - 1) / kWave);
+  if (bpart != nullptr && gx < (unsigned)net->O) gx = (unsigned)net->O;
+  hipLaunchKernelGGL(vjp_reduce_kernel, dim3(gx, V + (bpart != nullptr ? 1 : 0)), dim3(256), 0, s, part, g_centers,
+                     g_log_sigs, g_kernel, QSB, V, Npad, net->N, net->K, net->R, net->D, net->DC, net->O, bpart, g_bias, bias_blocks);
   IRBFN_HIP_CHECK(hipGetLastError());
   if (net->R > 1) {
     hipLaunchKernelGGL(vjp_reduce_regions_kernel, dim3(net->K, net->O), dim3(kWave), 0, s, part, g_kernel, Npad, net->K, net->R,
@@ -335,21 +355,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
     if (threadIdx.x == 0) bmax[blockIdx.x] = smax[0];
   }
-}
-
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ g_bias,
-                                                            int nblocks, int O) {
-  __shared__ float sm[256];
-  const int o = blockIdx.x, t = threadIdx.x;
-  float s = 0.0f;
-  for (int b = t; b < nblocks; b += 256) s += part[(size_t)b * O + o];
-  sm[t] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {             // fixed tree -> deterministic
-    if (t < w) sm[t] += sm[t + w];
-    __syncthreads();
-  }
-  if (t == 0) g_bias[o] = sm[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -738,25 +743,26 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     IRBFN_HIP_CHECK(hipGetLastError());
     int rch;
     const int* run_if = nullptr;
+    int run_gen = 0;
     if (p.use_g) {
       // K2g first; a query outside its representable box raises the flag, K2g returns at once and K2h -- launched behind it
       // with the complementary test -- does the work
-      int* flag = reinterpret_cast<int*>(scales + 4);
+      // The flag is a generation number in a small ring of net-owned words (zero at creation): call `gen` stores gen into word
+      // gen % 64 when it has such a query, nobody resets anything -- a memset per call was a launch of its own.
+      if (++net->vjp_gen <= 0) net->vjp_gen = 1;
+      run_gen = net->vjp_gen;
+      int* flag = net->vjp_flags + (run_gen & 63);
       rch = launch_vjp_gram(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks, scales, flag,
-                            part, p.QSB, p.Npad, s);
+                            run_gen, part, p.QSB, p.Npad, s);
       if (rch != IRBFN_OK) return rch;
       run_if = flag;
     } else if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2G) {
       return IRBFN_ERR_UNSUPPORTED;
     }
     rch = launch_vjp_f16(net, x, gout, B, reinterpret_cast<unsigned char*>(base + p.off_qblk), bmax, p.bias_blocks,
-                         scales, part, p.QSB, p.Npad, p.CT, s, run_if);
+                         scales, part, p.QSB, p.Npad, p.CT, s, run_if, run_gen);
     if (rch != IRBFN_OK) return rch;
-    rch = launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s);
-    if (rch != IRBFN_OK) return rch;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
-    IRBFN_HIP_CHECK(hipGetLastError());
-    return IRBFN_OK;
+    return launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s, bpart, g_bias, p.bias_blocks);
   }
 
   if (p.use_sp && !gamma_ext) {
@@ -765,14 +771,10 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
     int rcs = launch_vjp_sparse(net, x, gout, B, base + p.off_sp, sp_part, p.SL, p.Npad, s);
     if (rcs != IRBFN_ERR_UNSUPPORTED) {
       if (rcs != IRBFN_OK) return rcs;
-      rcs = launch_vjp_reduce(net, sp_part, g_centers, g_log_sigs, g_kernel, p.SL, p.V, p.Npad, s);
-      if (rcs != IRBFN_OK) return rcs;
       hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
                          (long)B, net->O, p.rows_per_block, (float*)nullptr);
       IRBFN_HIP_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
-      IRBFN_HIP_CHECK(hipGetLastError());
-      return IRBFN_OK;
+      return launch_vjp_reduce(net, sp_part, g_centers, g_log_sigs, g_kernel, p.SL, p.V, p.Npad, s, bpart, g_bias, p.bias_blocks);
     }
     if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2R) return IRBFN_ERR_UNSUPPORTED;
   } else if (net->opt[IRBFN_OPT_VJP_KERNEL] == IRBFN_VJP_K2R && !gamma_ext) {
@@ -803,14 +805,10 @@ int launch_vjp(irbfn_net* net, const float* x, const float* gout, float* g_cente
   }
   if (rc != IRBFN_OK) return rc;
 
-  rc = launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s);
-  if (rc != IRBFN_OK) return rc;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.bias_blocks), dim3(256), 256 * sizeof(float), s, gout, bpart,
                      (long)B, net->O, p.rows_per_block, (float*)nullptr);
   IRBFN_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(net->O), dim3(256), 0, s, bpart, g_bias, p.bias_blocks, net->O);
-  IRBFN_HIP_CHECK(hipGetLastError());
-  return IRBFN_OK;
+  return launch_vjp_reduce(net, part, g_centers, g_log_sigs, g_kernel, p.QSB, p.V, p.Npad, s, bpart, g_bias, p.bias_blocks);
 }
 
 }  // namespace irbfn

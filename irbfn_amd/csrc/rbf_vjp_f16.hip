@@ -45,8 +45,8 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_kernel(const float* __rest
                                                              const float* __restrict__ bmax, int nbmax,
                                                              const float* __restrict__ oscale,
                                                              unsigned char* __restrict__ qblk, float* __restrict__ scales,
-                                                             GateTables gt, long B, int D, int RFQ, int O, const int* __restrict__ run_if) {
-  if (run_if != nullptr && *run_if == 0) return;             // K2g did the work
+                                                             GateTables gt, long B, int D, int RFQ, int O, const int* __restrict__ run_if, int run_gen) {
+  if (run_if != nullptr && *run_if != run_gen) return;             // K2g did the work
   const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
   const long q0 = (long)blockIdx.x * 32;
   const int blkb = 32 * RFQ * 4 + 4096;
@@ -134,7 +134,8 @@ struct VjpHArgs {
   long nqb;
   int O, OP, N, S, Npad, basis, bpw;
   float gscale;
-  const int* __restrict__ run_if;           // null, or: return at once while *run_if == 0 (K2g did the work)
+  const int* __restrict__ run_if;           // null, or: return at once unless *run_if == run_gen (K2g did the work)
+  int run_gen;
 };
 
 #ifndef IRBFN_K2H_MINW
@@ -143,7 +144,7 @@ struct VjpHArgs {
 template <int DC, int BC, int CT>
 __global__ __launch_bounds__(256, CT == 2 ? IRBFN_K2H_MINW : 2) void rbf_vjp_f16mfma(const VjpHArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  if (a.run_if != nullptr && *a.run_if == 0) return;
+  if (a.run_if != nullptr && *a.run_if != a.run_gen) return;
   constexpr int RFQ = vjph_rfq(DC);
   constexpr int QXB = 32 * RFQ * 4;
   constexpr int BLKB = QXB + 4096;
@@ -382,11 +383,11 @@ static int launch_vjph_dc(const VjpHArgs& a, int CT, int bc, dim3 grid, size_t l
 // x, gout -> slabs part[QSB][V][Npad] (QSB query-slice blocks of 4 waves).  qblk / scales: workspace; bmax: per-block
 // max |g| written by colsum_partial_kernel (no separate reduction pass, no atomics).
 int launch_vjp_f16(irbfn_net* net, const float* x, const float* gout, int64_t B, unsigned char* qblk, const float* bmax,
-                   int nbmax, float* scales, float* part, int QSB, int Npad, int CT, hipStream_t s, const int* run_if) {
+                   int nbmax, float* scales, float* part, int QSB, int Npad, int CT, hipStream_t s, const int* run_if, int run_gen) {
   if (!vjph_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
   const long nqb = (B + 31) / 32;
   hipLaunchKernelGGL(vjp_pack_blocks_kernel, dim3((unsigned)nqb), dim3(64), 0, s, x, gout, bmax, nbmax, net->f16_oscale,
-                     qblk, scales, net->gate(), (long)B, net->D, vjph_rfq(net->DC), net->O, run_if);
+                     qblk, scales, net->gate(), (long)B, net->D, vjph_rfq(net->DC), net->O, run_if, run_gen);
   IRBFN_HIP_CHECK(hipGetLastError());
   VjpHArgs a;
   a.qblk = qblk; a.scales = scales; a.rec = net->rec; a.sig2 = net->sig2; a.oscale = net->f16_oscale; a.part = part;
@@ -394,7 +395,7 @@ int launch_vjp_f16(irbfn_net* net, const float* x, const float* gout, int64_t B,
   const long slices = (long)QSB * 4;
   a.bpw = (int)((nqb + slices - 1) / slices);
   a.gscale = gauss_scale(net->basis);
-  a.run_if = run_if;
+  a.run_if = run_if; a.run_gen = run_gen;
   const int groups = (net->N + 16 * CT - 1) / (16 * CT);
   const dim3 grid(groups, QSB);
   const int V = net->DC + 1 + net->OP;

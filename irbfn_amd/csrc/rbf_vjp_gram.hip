@@ -41,16 +41,43 @@ __device__ __forceinline__ float vg_pow2_ceil_scale(float mx) {
   return ldexpf(1.0f, e);
 }
 
-// ---- pre-pass: one 64-lane block per 32-query block ---------------------------------------------------------------
+// ---- pre-pass: one block of three waves per 32-query block: wave 0 the query-side operands of u, wave 1 the A operands of hbar,
+// wave 2 the dW / dC operands -- three short dependent chains side by side instead of one long one (one wave per block: 20 us at
+// config 3, all of it a single wave's latency) ----------------------------------------------------------------------
 template <int DC>
-__global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+__global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* __restrict__ x, const float* __restrict__ gout,
                                                                   const float* __restrict__ bmax, int nbmax,
                                                                   const float* __restrict__ oscale, const GramHdr* __restrict__ hdr,
                                                                   unsigned char* __restrict__ qblk, float* __restrict__ scales,
-                                                                  int* __restrict__ flag, GateTables gt, long B, int D, int O) {
-  const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+                                                                  int* __restrict__ flag, int gen, GateTables gt, long B, int D, int O) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long q0 = (long)blockIdx.x * 32;
   unsigned char* p = qblk + (size_t)blockIdx.x * kVgBlock;
+  // query-side operands of u for the halves s = 0, 1 (queries q0 + 16 s + n): K1g's, as A operands here
+  if (role == 0) {
+    F16Args a;
+    a.x = x; a.B = B; a.Dreal = D;
+    long qrow[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      long q = q0 + 16 * s + n;
+      q = q < B ? q : B - 1;
+      qrow[s] = q < 0 ? 0 : q;
+    }
+    h4_t bhd[2];
+    h8_t btl[2][2];
+    const bool bad = gram_query_operands<DC>(a, hdr, qrow, g, bhd, btl);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicExch(flag, gen);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned char* ps = p + s * (kVgDist / 2);
+      *reinterpret_cast<h4_t*>(ps + lane * 8) = bhd[s];
+      *reinterpret_cast<h8_t*>(ps + 512 + lane * 16) = btl[s][0];
+      *reinterpret_cast<h8_t*>(ps + 512 + 1024 + lane * 16) = btl[s][1];
+    }
+    return;
+  }
   float mx = 0.0f;                             // max |g| over the batch from the per-block maxima of colsum_partial_kernel
   for (int i = lane; i < nbmax; i += 64) {
     const float v = bmax[i];
@@ -65,7 +92,7 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* _
   float somax = 0.0f;
   for (int o = 0; o < O; ++o) somax = fmaxf(somax, oscale[o]);
   const float sh = sg * somax;
-  if (blockIdx.x == 0 && lane == 0) { scales[0] = sg; scales[1] = sh; }
+  if (blockIdx.x == 0 && role == 1 && lane == 0) { scales[0] = sg; scales[1] = sh; }
   // gate of the single region (model.py:42-95) of query q0 + lane (lanes >= 32: 0)
   float gm = 0.0f;
   if (lane < 32 && q0 + lane < B) {
@@ -76,35 +103,13 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* _
       gm *= gate_factor(x[q * D + d], gt.lo[e], gt.hi[e], gt.delta[d]);
     }
   }
-  // query-side operands of u for the halves s = 0, 1 (queries q0 + 16 s + n): K1g's, as A operands here
-  {
-    F16Args a;
-    a.x = x; a.B = B; a.Dreal = D;
-    long qrow[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      long q = q0 + 16 * s + n;
-      q = q < B ? q : B - 1;
-      qrow[s] = q < 0 ? 0 : q;
-    }
-    h4_t bhd[2];
-    h8_t btl[2][2];
-    const bool bad = gram_query_operands<DC>(a, hdr, qrow, g, bhd, btl);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(flag, 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      unsigned char* ps = p + s * (kVgDist / 2);
-      *reinterpret_cast<h4_t*>(ps + lane * 8) = bhd[s];
-      *reinterpret_cast<h8_t*>(ps + 512 + lane * 16) = btl[s][0];
-      *reinterpret_cast<h8_t*>(ps + 512 + 1024 + lane * 16) = btl[s][1];
-    }
-  }
   // A operands of the hbar MFMAs per half (rows = queries 16 s + n), v = gamma_q g / s_h x s_o as an (hi, lo) pair:
   //   A1 (16x16x16): k = output 4 g + j, hi                     x  W hi
   //   A2 (16x16x32): k = 8 g + j: (g < 2: lo, g >= 2: hi) of output 8 (g & 1) + j   x  (W hi | W lo) -- lo x hi + hi x lo in ONE MFMA
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
   h4v* gA1 = reinterpret_cast<h4v*>(p + kVgDist);
   h8_t* gA2 = reinterpret_cast<h8_t*>(p + kVgDist + 1024);
+  if (role == 1) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const long q = q0 + 16 * s + n;
@@ -131,6 +136,8 @@ __global__ __launch_bounds__(64) void vjp_pack_blocks_gram_kernel(const float* _
     }
     gA1[s * 64 + lane] = hi;
     gA2[s * 64 + lane] = mix;
+  }
+  return;
   }
   // A operand of the dW MFMA (16x16x32): rows = outputs n, k = 8 g + j <-> query 16 (j >> 2) + 4 g + (j & 3), gamma_q g / s_g
   // B operand of the dC MFMA (16x16x32): k as above, cols = coordinate n of x' / 2^ex (n < D), 1 (n = 8), 0
@@ -163,7 +170,8 @@ struct VjpGArgs {
   const float* __restrict__ scales;         // [0] = s_g, [1] = s_h
   const unsigned char* __restrict__ gimg;   // K1g's chunk images: centre-side operands of u
   const GramHdr* __restrict__ hdr;
-  const int* __restrict__ flag;             // != 0: a query outside the box -- K2h does the work
+  const int* __restrict__ flag;             // == gen: a query of THIS call outside the box -- K2h does the work
+  int gen;
   const float* __restrict__ rec;            // [N][S] K1 records: c[DC], scale, W[OP]
   const float* __restrict__ sig2;           // [N]
   const float* __restrict__ oscale;         // [O]
@@ -180,7 +188,7 @@ struct VjpGArgs {
 template <int DC, int BC>
 __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  if (*a.flag != 0) return;
+  if (*a.flag == a.gen) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
@@ -390,22 +398,21 @@ static int launch_vjpg_dc(const VjpGArgs& a, int bc, dim3 grid, size_t lds, hipS
 
 // x, gout -> slabs part[QSB][V][Npad].  qblk / scales / flag: workspace; bmax: per-block max |g| written by colsum_partial_kernel
 int launch_vjp_gram(irbfn_net* net, const float* x, const float* gout, int64_t B, unsigned char* qblk, const float* bmax, int nbmax,
-                    float* scales, int* flag, float* part, int QSB, int Npad, hipStream_t s) {
+                    float* scales, int* flag, int gen, float* part, int QSB, int Npad, hipStream_t s) {
   if (!vjpg_eligible(net)) return IRBFN_ERR_UNSUPPORTED;
   const long nqb = (B + 31) / 32;
   const GramHdr* hdr = reinterpret_cast<const GramHdr*>(net->gram_hdr);
-  IRBFN_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
-  const dim3 pg((unsigned)nqb), pb(64);
+  const dim3 pg((unsigned)nqb), pb(192);
   switch (net->DC) {
-    case 3: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<3>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
-    case 4: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<4>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
-    case 7: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<7>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
-    case 8: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<8>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, net->gate(), (long)B, net->D, net->O); break;
+    case 3: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<3>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
+    case 4: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<4>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
+    case 7: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<7>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
+    case 8: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<8>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
   VjpGArgs a;
-  a.qblk = qblk; a.scales = scales; a.gimg = net->gram_img; a.hdr = hdr; a.flag = flag; a.rec = net->rec; a.sig2 = net->sig2;
+  a.qblk = qblk; a.scales = scales; a.gimg = net->gram_img; a.hdr = hdr; a.flag = flag; a.gen = gen; a.rec = net->rec; a.sig2 = net->sig2;
   a.oscale = net->f16_oscale; a.part = part;
   a.nqb = nqb; a.O = net->O; a.OP = net->OP; a.N = net->N; a.S = net->S; a.Npad = Npad;
   a.bpb = (int)((nqb + QSB - 1) / QSB);
