@@ -128,7 +128,9 @@ typedef enum irbfn_option {
                                   1: only the first one does and later calls keep its verdict -- for training loops, which re-bind every step.
                                   The kernels test the device-side verdict themselves and fall back to the VALU distances / to K2h, so a stale
                                   host verdict costs speed, never correctness */
-  IRBFN_OPT_COUNT = 15
+  IRBFN_OPT_VJP_QSB = 15,      /* K2g / K2h: query slices of the VJP grid (slabs summed in fixed order); 0 (default): automatic.  Never more than
+                                  the workspace was sized for (the automatic number of the all-float32 kernel) */
+  IRBFN_OPT_COUNT = 16
 } irbfn_option;
 typedef enum irbfn_fwd_kernel {
   IRBFN_FWD_AUTO = 0, /* B <= 64: K1s; sparse multi-region gate: K1r; one region + fast basis: K1g (d <= 8, parameters inside its budget; O <= 16:

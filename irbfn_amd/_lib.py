@@ -20,7 +20,7 @@ ROLLOUT_ST_SELECT, ROLLOUT_ST_KS, ROLLOUT_FULLINT, ROLLOUT_FRENET_LS, ROLLOUT_SP
 
 # irbfn_option / irbfn_fwd_kernel / irbfn_vjp_kernel (include/irbfn_hip.h)
 OPTIONS = {"fwd_kernel": 0, "fwd_small": 1, "fwd_f16_terms": 2, "fwd_f16_minb": 3, "fwd_q": 4, "fwd_nw": 5, "fwd_qj": 6,
-           "fwd_f16_s": 7, "fwd_f16_qg": 8, "vjp_kernel": 9, "vjp_f16_ct": 10, "lds_pad": 11, "fwd_wide_pipe": 12, "tick_fused": 13, "gram_sticky": 14}
+           "fwd_f16_s": 7, "fwd_f16_qg": 8, "vjp_kernel": 9, "vjp_f16_ct": 10, "lds_pad": 11, "fwd_wide_pipe": 12, "tick_fused": 13, "gram_sticky": 14, "vjp_qsb": 15}
 FWD_AUTO, FWD_K1, FWD_K1M, FWD_K1H, FWD_K1R, FWD_K1G = 0, 1, 2, 3, 4, 5
 VJP_AUTO, VJP_K2, VJP_K2H, VJP_K2R, VJP_K2G = 0, 1, 2, 3, 4
 

@@ -160,6 +160,7 @@ int irbfn_net_set_option(irbfn_net* net, int option, int value) {
     case IRBFN_OPT_VJP_F16_CT: if (value != 0 && value != 2 && value != 4) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_LDS_PAD: if (value > 128 * 1024) return IRBFN_ERR_BAD_ARG; break;
     case IRBFN_OPT_GRAM_STICKY: if (value > 1) return IRBFN_ERR_BAD_ARG; break;
+    case IRBFN_OPT_VJP_QSB: if (value > 4096) return IRBFN_ERR_BAD_ARG; break;
     default: break;
   }
   net->opt[option] = value;

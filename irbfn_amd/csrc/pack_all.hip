@@ -209,11 +209,12 @@ __device__ __forceinline__ void f16_image_body(const PackArgs& a, int vb) {
 __device__ inline double gram_pow2(int e) {                  // 2^e, -1022 <= e <= 1023, without the library's ldexp
   return __builtin_bit_cast(double, (unsigned long long)(1023 + e) << 52);
 }
-__device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e
+__device__ inline int gram_exp_above(double v) {            // smallest e with |v| < 2^e: v = f 2^e, f in [0.5, 1) (frexp's e)
   if (!(v > 0.0)) return -40;
-  int e;
-  (void)frexp(v, &e);                                        // v = f 2^e, f in [0.5, 1)
-  return e;
+  const int be = (int)((__builtin_bit_cast(unsigned long long, v) >> 52) & 0x7ff);
+  if (be == 0) return -1022;                                 // subnormal: far below anything the checks below accept
+  if (be == 0x7ff) return 1025;                              // Inf: refused by the range checks
+  return be - 1022;
 }
 
 // origin, exponents and the exactness budget of the expansion from the folded statistics tot[kStatsVals]
@@ -241,9 +242,9 @@ __device__ inline GramHdr gram_header(const float* tot, int D, int bclass, float
   // exactness budget of the head sum: the sum of the magnitudes of its terms -- a bound on every partial sum of the adder
   // tree -- stays below 2^24 grid units, grid = 2^(ex + ec - 20).  |x'_i| < 2^ex is what the kernel lets through.  A coarser
   // grid (ec + 1: heads of C one bit shorter, its tails one bit larger) buys a factor of two.
-  const double xb = ldexp(1.0, h.ex);
+  const double xb = gram_pow2(h.ex);                         // -40 <= ex <= 128 here (float inputs)
   const double worst = ((double)fa * D * xb * xb + (double)D * fC * xb + (double)f2) * (1.0 + 1.0 / 256.0);
-  while (worst >= ldexp(1.0, h.ex + h.ec + 4) && h.ec < 40) ++h.ec;
+  while (h.ec < 40 && worst >= gram_pow2(h.ex + h.ec + 4 < -1000 ? -1000 : (h.ex + h.ec + 4 > 1000 ? 1000 : h.ex + h.ec + 4))) ++h.ec;
   h.eq = 2 * h.ex + dbits;
   if (h.eq + h.ea < h.ex + h.ec) h.eq = h.ex + h.ec - h.ea;                 // Q x alpha heads on the cross grid
   h.e2 = gram_exp_above(f2 * 1.0000002);
@@ -302,7 +303,7 @@ __device__ __forceinline__ void gram_image_body(const PackArgs& a, int c, unsign
   const int CB = gram_chunk_bytes(NT);
   unsigned char* p = simg;
   for (int it = tid; it < kF16Chunk * 16; it += kPackBlock) {
-    const int kk = it >> 4, part = it & 15;
+    const int part = it >> 5, kk = it & 31;                  // a wave = two parts x 32 centres: (nearly) one path per wave
     const int n = c * kF16Chunk + kk;
     const bool real = n < a.N;
     const int ct = kk >> 4, row = kk & 15;                   // centre tile, A-operand row

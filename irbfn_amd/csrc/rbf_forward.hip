@@ -303,14 +303,18 @@ bool gram_wide_preferred(const irbfn_net* net, int64_t B) {
 // 35 KiB of LDS per slice).  Measured at the config-2 net (profiles/r03_gram_batch_sweep.txt; us at B = 16384 / 24576 / 32768 /
 // 65536 / 131072 / 262144): S = 4, QG = 2: 38 / 70 / 72 / 139 / 275 / 547; S = 2, QG = 4: 53 / 53 / 55 / 82 / 155 / 298; S = 1, QG = 8:
 // 88 / 88 / 88 / 88 / 142 / 273 -- more slices while the launch is short of waves, never more blocks than are resident at once.
+// Between one and one and a half rounds of the S = 2 form (2048 < groups <= 3072: the reference's training batch of 80000) a
+// second, thin round of blocks costs a wave's whole latency-bound pass over its slice; blocks of FOUR waves with all the centres
+// (S = 1, QG = 4: four resident per CU, 4096 groups at once) spread the same work over the chip in one round
+// (profiles/r03_gram_geometry_sweep.txt: N = 1000, B = 80000: 40.7 vs 47.4 us; N = 2048: 67 vs 73; N = 4096: 121 vs 122).
 void gram_geometry(const irbfn_net* net, int64_t B, int* S_out, int* QG_out) {
   const long groups = (B + 31) / 32;
   const int nchunks = (net->N + 31) / 32;
-  int S = groups <= 512 ? 4 : (groups <= 3072 ? 2 : 1);
+  int S = groups <= 512 ? 4 : (groups <= 2048 ? 2 : 1);
   while (S > 1 && nchunks / (2 * S) < 4) S /= 2;            // at least 8 chunks per wave
   S = opt_or(net, IRBFN_OPT_FWD_F16_S, S);
   if (S > 7 || S > nchunks) S = 1;
-  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, 8 / S);
+  int QG = opt_or(net, IRBFN_OPT_FWD_F16_QG, (S == 1 && groups > 2048 && groups <= 3072) ? 4 : 8 / S);
   if (S * QG > 16) QG = 1;
   *S_out = S; *QG_out = QG;
 }

@@ -416,11 +416,14 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
     off += al((size_t)p.SL * p.V * p.Npad * sizeof(float));
   }
   if (p.use_g) {
-    // K2g: a block = 4 waves = 128 centres; slices so that the launch has ~4096 waves, at least 8 query blocks each
+    // K2g: a block = 4 waves = 128 centres; slices so that the launch is ONE resident round (3 waves per SIMD: 768 blocks), at
+    // least 8 query blocks each (profiles/r03_vjp_qsb_sweep.txt: config 3 198 -> 195 us, the reference's 1000-centre net at
+    // B = 80000 107 -> 101 us against 1024 blocks)
     const long nqb = (B + 31) / 32;
     const long gb = ((net->N + 31) / 32 + 3) / 4;
-    long q2 = (1024 + gb - 1) / gb;
+    long q2 = (768 + gb - 1) / gb;
     if (q2 * 8 > nqb) q2 = (nqb + 7) / 8;
+    if (net->opt[IRBFN_OPT_VJP_QSB] > 0) q2 = net->opt[IRBFN_OPT_VJP_QSB];
     if (q2 < 1) q2 = 1;
     if (q2 < p.QSB) p.QSB = (int)q2;          // never more slabs than were allocated above
   } else if (p.use_h) {

@@ -189,10 +189,13 @@ template <int DC, int BC>
 __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   if (*a.flag == a.gen) return;
+  // (centre block, query slice) in plain grid order: placing the blocks that stream the same query slice on one XCD -- one L2 --
+  // was measured and changes nothing (profiles/r03_vjp_qsb_sweep.txt): the 12 KiB query blocks are not what the kernel waits for
+  const int bx = blockIdx.x, by = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
-  const int chunk = blockIdx.x * 4 + wave;                   // this wave's 32 centres
+  const int chunk = bx * 4 + wave;                   // this wave's 32 centres
   const bool active = chunk < a.nchunks;
   const int cb = chunk * 32;
   const float sg = a.scales[0], sh = a.scales[1];
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) { dW[ct] = f4_t{0, 0, 0, 0}; dWl[ct] = f4_t{0, 0, 0, 0}; dC[ct] = f4_t{0, 0, 0, 0}; dCl[ct] = f4_t{0, 0, 0, 0}; }
 
-  const long qb0 = (long)blockIdx.y * a.bpb;
+  const long qb0 = (long)by * a.bpb;
   long qb1 = qb0 + a.bpb;
   qb1 = qb1 < a.nqb ? qb1 : a.nqb;
   const int nb = qb1 > qb0 ? (int)(qb1 - qb0) : 0;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
 
   // ---- this wave's 32 centres: slab rows (format of rbf_vjp_kernel): d centers [0, DC), d log_sigs DC, d kernel DC + 1 + o
   const int V = DC + 1 + a.OP;
-  float* dst = a.part + (size_t)blockIdx.y * V * a.Npad;
+  float* dst = a.part + (size_t)by * V * a.Npad;
   const float wscale = sg * (1.0f / (PS * kWScale));         // s_g / (scale of the basis values x 2^15)
   const float xs = __builtin_ldexpf(1.0f, a.hdr->ex - kWExp);   // x' operand: x' 2^-ex 2^15
 #pragma unroll

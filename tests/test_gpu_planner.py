@@ -177,7 +177,8 @@ def test_waypoint_geometry_matches_the_restatement(gpu):
 @pytest.mark.parametrize("mode_name,D,T,B,basis", [
     ("st_ks", 7, 5, 4099, "gaussian"), ("st_select", 7, 5, 70000, "gaussian"), ("st_ks", 7, 1, 1000, "gaussian"),
     ("st_ks", 7, 8, 333, "inverse_quadratic"), ("fullint", 7, 5, 2500, "inverse_multiquadric"), ("frenet", 8, 5, 4099, "gaussian"),
-    ("frenet", 8, 5, 129, "inverse_quadratic"), ("frenet", 8, 2, 20000, "inverse_multiquadric")])
+    ("frenet", 8, 5, 129, "inverse_quadratic"), ("frenet", 8, 2, 20000, "inverse_multiquadric"),
+    ("fullint", 7, 5, 80000, "gaussian"), ("frenet", 8, 5, 66000, "gaussian")])       # 2048 < B / 32 <= 3072: blocks of four waves (S = 1, QG = 4)
 def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B, basis):
     """The planning tick of the narrow nets on the matrix-core kernel (`rbf_tick_f16mfma`: forward + sign flip + roll-out
     by the wave that produced the rows): controls and states equal, bit for bit, the forward followed by the stand-alone
@@ -214,6 +215,8 @@ def test_narrow_tick_in_one_launch(gpu, mode_name, D, T, B, basis):
     ctrl, states = plan_tick(net, P, xt, mt, st, configs.DYN_PARAMS, mode=mode)
     tick_kernel = net.last_launch()["kernel"]               # K1g where the parameters fit its expansion and d = 7, else K1h
     assert tick_kernel.startswith("rbf_tick_f16gram<") or tick_kernel.startswith("rbf_tick_f16mfma<")
+    if tick_kernel.startswith("rbf_tick_f16gram<") and 2048 * 32 < B <= 3072 * 32:
+        assert "S=1,QG=4" in tick_kernel, tick_kernel
     u = net.apply(P, xt).clone()
     assert net.last_launch()["kernel"].startswith(tick_kernel.split("<")[0].replace("tick", "fwd") + "<")
     ref = co.wcrbf_forward(cfg, P, x, np.float64)

@@ -1,7 +1,7 @@
 """ONE kernel at ONE batch size, N launches: the unit of a per-(kernel, batch size) rocprofv3 summary
     rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/run_one.py <what> <B> [launches]
 what: fwd_cfg2[_k1h|_k1g] | fwd_cfg4_wide | tick_cfg4 | vjp_cfg3 | train_cfg3 | roll_<mode> | rollvjp_<mode> | spiral | spiralvjp | sparse_fwd |
-      sparse_tick | sparse_vjp | sparse_train      (mode: st_ks, st_select, fullint, frenet; T = 50, spiral N = 9)"""
+      sparse_tick | sparse_vjp | sparse_train | train_1region      (mode: st_ks, st_select, fullint, frenet; T = 50, spiral N = 9)"""
 import json
 import os
 import sys
@@ -77,8 +77,8 @@ elif what in ("spiral", "spiralvjp"):
     q = torch.from_numpy(np.hstack([rng.normal(0, 0.3, (B, 4)), rng.uniform(2, 10, (B, 1))]).astype(np.float32)).cuda()
     gs = torch.from_numpy(rng.normal(size=(B, N, 6)).astype(np.float32)).cuda()
     fn = (lambda: dynamics.rollout_forward(_lib.ROLLOUT_SPIRAL, q, None, N)) if what == "spiral" else (lambda: dynamics.rollout_vjp(_lib.ROLLOUT_SPIRAL, q, None, gs, N))
-elif what.startswith("sparse_"):
-    net, P, x = trained()
+elif what.startswith("sparse_") or what == "train_1region":
+    net, P, x = trained("dnmpc_1regions_newdata_oldintloss_nomirror_highk") if what == "train_1region" else trained()
     Pd = distributed.params_to_device(P)
     net.bind(Pd)
     if what == "sparse_fwd":
