@@ -42,8 +42,9 @@ __device__ __forceinline__ float vg_pow2_ceil_scale(float mx) {
 }
 
 // ---- pre-pass: one block of three waves per 32-query block: wave 0 the query-side operands of u, wave 1 the A operands of hbar,
-// wave 2 the dW / dC operands -- three short dependent chains side by side instead of one long one (one wave per block: 20 us at
-// config 3, all of it a single wave's latency) ----------------------------------------------------------------------
+// wave 2 the dW / dC operands -- three dependent chains side by side instead of one long one (one wave per block: 20 us at config 3;
+// now 17-19 us.  Ablation, roles switched off one by one: role 0 alone 8.4 us, role 1 alone 11.7, role 2 alone 9.9, all three 18.6 --
+// 6144 waves of > 64 VGPRs are a round and a half of the chip, so the chains overlap only in part) ----------------------------
 template <int DC>
 __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* __restrict__ x, const float* __restrict__ gout,
                                                                   const float* __restrict__ bmax, int nbmax,
