@@ -281,10 +281,8 @@ __device__ inline void gram_parts_c2(double v, int E, double (&n)[4]) {
   n[3] = (double)(_Float16)(float)r3;
 }
 
-// One block per chunk; sixteen work items per centre-in-chunk: item `part` < 8 fills the slots of coordinate `part` (1 head, 5
-// tails), item 8 the slots of Q x alpha and of c2 (3 heads, 7 tails), items 9..15 the empty slots; every item the W values of
-// output `part` of every column tile.
-static_assert(kGramDims + 3 <= 16 && 5 * kGramDims + 7 <= 64, "slots of the expansion");
+// One block per chunk; sixteen work items per centre-in-chunk: item `part` fills head slot `part` and the tail slots 4 part .. 4 part + 3
+// (rbf_forward_gram.h: the slot tables say which product sits where) and the W values of output `part` of every column tile.
 __device__ __forceinline__ void gram_image_body(const PackArgs& a, int c, unsigned char* simg, GramHdr& hs, float* tot) {
   const int tid = threadIdx.x;
   if (tid < kStatsVals) {
@@ -320,41 +318,35 @@ __device__ __forceinline__ void gram_image_body(const PackArgs& a, int c, unsign
       gram_alpha_beta(a.bclass, s2, a.gscale, alpha, beta);                 // every term of the expansion uses this one value
       if (!real) alpha = 0.0;                                // a padding centre: u = beta (P finite), its W rows are 0
     }
-    if (part < kGramDims) {
-      double nC[3] = {0.0, 0.0, 0.0};
-      if (real && h.ok && part < D) gram_parts_d(-2.0 * alpha * ((double)a.centers[(size_t)n * D + part] - (double)h.r[part]), h.ec, nC);
-      put_head(part, nC[0], h.ex + h.ec);
-#pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        const int q = gram_comb_q(m);
-        put_tail(5 * part + m, nC[q], h.ex + h.ec - 11 * (gram_comb_p(m) + q));
+    // centre-side factor of a slot's product: part q of C_dim = -2 alpha c'_dim, part q of alpha, part p of c2 = alpha |c'|^2 + beta
+    auto centre_value = [&](const GramSlot sl) -> double {
+      if (!h.ok || sl.kind == 0) return 0.0;
+      if (sl.kind == 1) {
+        double nC[3] = {0.0, 0.0, 0.0};
+        if (real && sl.dim < D) gram_parts_d(-2.0 * alpha * ((double)a.centers[(size_t)n * D + sl.dim] - (double)h.r[sl.dim]), h.ec, nC);
+        return sl.q == 0 ? nC[0] : (sl.q == 1 ? nC[1] : nC[2]);
       }
-    } else if (part == kGramDims) {
-      double nA[3] = {0.0, 0.0, 0.0}, n2[4] = {0.0, 0.0, 0.0, 0.0};
-      if (h.ok) {
-        double c2 = beta;
-        if (real)
-          for (int i = 0; i < D && i < kGramDims; ++i) {
-            const double cp = (double)a.centers[(size_t)n * D + i] - (double)h.r[i];
-            c2 += alpha * cp * cp;
-          }
+      if (sl.kind == 2) {
+        double nA[3];
         gram_parts_d(alpha, h.ea, nA);
-        gram_parts_c2(c2, h.e2, n2);
+        return sl.q == 0 ? nA[0] : (sl.q == 1 ? nA[1] : nA[2]);
       }
-      put_head(kGramDims, nA[0], h.eq + h.ea);
-      put_head(kGramDims + 1, n2[0], h.e2);
-      put_head(kGramDims + 2, n2[1], h.e2 - 11);
-#pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        const int q = gram_comb_q(m);
-        put_tail(5 * kGramDims + m, nA[q], h.eq + h.ea - 11 * (gram_comb_p(m) + q));
-      }
-      put_tail(5 * kGramDims + 5, n2[2], h.e2 - 22);
-      put_tail(5 * kGramDims + 6, n2[3], h.e2 - 33);
-    } else {                                                 // the empty slots, spread over items 9..15
-      const int z = part - (kGramDims + 1);
-      for (int s = kGramDims + 3 + z; s < 16; s += 15 - kGramDims) put_head(s, 0.0, 0);
-      for (int s = 5 * kGramDims + 7 + z; s < 64; s += 15 - kGramDims) put_tail(s, 0.0, 0);
+      double c2 = beta, n2[4];
+      if (real)
+        for (int i = 0; i < D && i < kGramDims; ++i) {
+          const double cp = (double)a.centers[(size_t)n * D + i] - (double)h.r[i];
+          c2 += alpha * cp * cp;
+        }
+      gram_parts_c2(c2, h.e2, n2);
+      return sl.p == 0 ? n2[0] : (sl.p == 1 ? n2[1] : (sl.p == 2 ? n2[2] : n2[3]));
+    };
+    {
+      const GramSlot sl = gram_head_slot(part);
+      put_head(part, centre_value(sl), gram_T(h, sl));
+    }
+    for (int i = 0; i < 4; ++i) {
+      const GramSlot sl = gram_tail_slot(4 * part + i);
+      put_tail(4 * part + i, centre_value(sl), gram_T(h, sl));
     }
     // W rows in the k order of the Phi x W product: centre 16 ct + 4 g + r <-> k = 8 g + 4 ct + r
     const int g = row >> 2, j = ct * 4 + (row & 3);

@@ -31,19 +31,28 @@ struct GramHdr {
 };
 
 // ---- the slot tables: which product sits in which k-slot ---------------------------------------------------------
+// A lane of an operand holds the slots of ONE lane group g = lane >> 4: head slots 4 g + j (j < 4), tail slots 32 hf + 8 g + j (j < 8).
+// The products of coordinate i live with group i / 2 -- its head in head slot 4 (i / 2) + (i & 1), its five tail combinations in tail
+// slots 32 (i & 1) + 8 (i / 2) + m -- so a lane of the query side splits just ITS two coordinates (gram_query_operands); the
+// Q x alpha and 1 x c2 products fill free slots of the groups 0..2.  (Until round 3's last version the slots ran coordinate by
+// coordinate across the groups: every lane split all eight coordinates and selected -- 700 instructions of prologue per wave.)
 struct GramSlot { int kind, dim, p, q; };        // kind: 0 empty, 1 x'_dim part p x C part q, 2 Q part p x alpha part q, 3 1 x c2 part p
-__host__ __device__ constexpr GramSlot gram_head_slot(int s) {
-  return s < kGramDims ? GramSlot{1, s, 0, 0}
-                       : (s == kGramDims ? GramSlot{2, 0, 0, 0}
-                                         : (s == kGramDims + 1 ? GramSlot{3, 0, 0, 0} : (s == kGramDims + 2 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})));
-}
 __host__ __device__ constexpr int gram_comb_p(int m) { return m == 0 ? 0 : (m == 1 ? 1 : (m == 2 ? 0 : (m == 3 ? 2 : 1))); }
 __host__ __device__ constexpr int gram_comb_q(int m) { return m == 0 ? 1 : (m == 1 ? 0 : (m == 2 ? 2 : (m == 3 ? 0 : 1))); }
-__host__ __device__ constexpr GramSlot gram_tail_slot(int s) {
-  return s < 5 * kGramDims ? GramSlot{1, s / 5, gram_comb_p(s % 5), gram_comb_q(s % 5)}
-                           : (s < 5 * kGramDims + 5 ? GramSlot{2, 0, gram_comb_p(s - 5 * kGramDims), gram_comb_q(s - 5 * kGramDims)}
-                                                    : (s < 5 * kGramDims + 7 ? GramSlot{3, 0, s - 5 * kGramDims - 5 + 2, 0} : GramSlot{0, 0, 0, 0}));
+__host__ __device__ constexpr GramSlot gram_head_slot(int s) {
+  const int g = s >> 2, j = s & 3;
+  return j < 2 ? GramSlot{1, 2 * g + j, 0, 0}
+               : (j == 2 ? (g == 0 ? GramSlot{2, 0, 0, 0} : (g == 1 ? GramSlot{3, 0, 0, 0} : (g == 2 ? GramSlot{3, 0, 1, 0} : GramSlot{0, 0, 0, 0})))
+                         : GramSlot{0, 0, 0, 0});
 }
+__host__ __device__ constexpr GramSlot gram_tail_slot(int s) {
+  const int hf = s >> 5, g = (s >> 3) & 3, j = s & 7;
+  const int m = hf * 3 + (j - 5);                            // free slots of group 0: Q x alpha combinations 0..4, then the third c2 part
+  return j < 5 ? GramSlot{1, 2 * g + hf, gram_comb_p(j), gram_comb_q(j)}
+               : (g == 0 ? (m < 5 ? GramSlot{2, 0, gram_comb_p(m), gram_comb_q(m)} : GramSlot{3, 0, 2, 0})
+                         : (g == 1 && hf == 0 && j == 5 ? GramSlot{3, 0, 3, 0} : GramSlot{0, 0, 0, 0}));
+}
+static_assert(kGramDims == 8, "four lane groups x two coordinates");
 // power-of-two weight of a slot's product and its split between the two operands (both kept near 2^(T/2))
 __host__ __device__ inline int gram_T(const GramHdr& h, const GramSlot sl) {
   return sl.kind == 1 ? h.ex + h.ec - 11 * (sl.p + sl.q) : (sl.kind == 2 ? h.eq + h.ea - 11 * (sl.p + sl.q) : h.e2 - 11 * sl.p);
@@ -121,68 +130,96 @@ __device__ __forceinline__ void gram_parts_f(float vh, float vl, float inv, floa
 }
 
 // Query-side operands of the expansion for the wave's two query tiles (rows qrow[t] of x): B[k = slot][column = query (lane & 15)],
-// slots 4 g + j of the head MFMA, 32 hf + 8 g + j of the tail MFMAs (g = lane >> 4).  Returns whether THIS lane's queries fall
-// outside the representable box (|x'_i| >= 2^ex, Q >= 2^eq, NaN, Inf) or the header says the net does not fit.
+// slots 4 g + j of the head MFMA, 32 hf + 8 g + j of the tail MFMAs (g = lane >> 4).  A lane splits the two coordinates 2 g and
+// 2 g + 1 of its queries (the slot tables above put exactly their products into its slots); Q = |x'|^2 is summed in double-float
+// over the four lanes that hold a query's coordinates (a commutative butterfly: the four lanes end with the same bits).  Returns
+// whether THIS lane's coordinates fall outside the representable box (|x'_i| >= 2^ex, Q >= 2^eq, NaN, Inf) or the header says the
+// net does not fit -- the callers take the ballot of the wave.
 template <int DC>
 __device__ __forceinline__ bool gram_query_operands(const F16Args& a, const GramHdr* hp, const long (&qrow)[2], int g, h4_t (&bhd)[2],
                                                     h8_t (&btl)[2][2]) {
+  // The error-free sums below are written operation by operation: contracted into FMAs (hipcc's default, -ffp-contract=fast:
+  // th = qh + sh * sh as one fma, tb = th - qh as fma(-sh', sh', th) when qh is itself a product) they lose the low word of Q --
+  // 6e-8 of |x'|^2, which the cancellation against 2 c'x' and |c'|^2 turns into 4e-5 of the result for a query 28 widths from
+  // the origin of the expansion (tests/test_gpu_gram.py::test_gram_ill_conditioned_columns[outlier_far_centre])
+#pragma clang fp contract(off)
   static_assert(DC <= kGramDims, "eight coordinate slots");
   const int ex = hp->ex, ec = hp->ec, eq = hp->eq, ea = hp->ea, e2 = hp->e2;
   GramHdr hx;                                                // exponents only (gram_T)
   hx.ex = ex; hx.ec = ec; hx.eq = eq; hx.ea = ea; hx.e2 = e2;
   bool bad = hp->ok == 0;
-  {
-    const float xinv = __builtin_ldexpf(1.0f, -ex), qinv = __builtin_ldexpf(1.0f, -eq);
-    const float xlim = __builtin_ldexpf(1.0f, ex) * 0.999f, qlim = __builtin_ldexpf(1.0f, eq) * 0.999f;
+  const float xinv = __builtin_ldexpf(1.0f, -ex), qinv = __builtin_ldexpf(1.0f, -eq);
+  const float xlim = __builtin_ldexpf(1.0f, ex) * 0.999f, qlim = __builtin_ldexpf(1.0f, eq) * 0.999f;
+  auto scale_of = [&](const GramSlot sl) -> float { return sl.kind == 0 ? 0.0f : __builtin_ldexpf(1.0f, gram_ax(gram_T(hx, sl))); };
+  float rr[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float nx[kGramDims][3], nq[3];
-      float qh = 0.0f, ql = 0.0f;
+  for (int c = 0; c < 2; ++c) rr[c] = (2 * g + c < DC) ? -hp->r[2 * g + c] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < kGramDims; ++i) {
-        if (i < DC) {
-          const float xv = i < a.Dreal ? a.x[qrow[t] * a.Dreal + i] : 0.0f;
-          const float rr = -hp->r[i];
-          const float sh = xv + rr;                          // TwoSum: x' = sh + sl exactly
-          const float bb = sh - xv;
-          const float sl = (xv - (sh - bb)) + (rr - bb);
-          bad = bad || !(__builtin_fabsf(sh) < xlim);        // NaN / Inf / outside the box
-          gram_parts_f(sh, sl, xinv, nx[i]);
-          const float ph = sh * sh;                          // Q += x'^2 in double-float
-          const float pl = __builtin_fmaf(sh, sh, -ph) + 2.0f * sh * sl;
-          const float th = qh + ph;
-          const float tb = th - qh;
-          ql += ((qh - (th - tb)) + (ph - tb)) + pl;
-          qh = th;
-        } else {
-          nx[i][0] = nx[i][1] = nx[i][2] = 0.0f;
-        }
+  for (int t = 0; t < 2; ++t) {
+    float nx[2][3], nq[3];
+    float qh = 0.0f, ql = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int i = 2 * g + c;
+      const float xv = (i < DC && i < a.Dreal) ? a.x[qrow[t] * a.Dreal + i] : 0.0f;
+      const float sh = xv + rr[c];                           // TwoSum: x' = sh + sl exactly
+      const float bb = sh - xv;
+      const float sl = (xv - (sh - bb)) + (rr[c] - bb);
+      bad = bad || !(__builtin_fabsf(sh) < xlim);            // NaN / Inf / outside the box
+      gram_parts_f(sh, sl, xinv, nx[c]);
+      const float ph = sh * sh;                              // Q += x'^2 in double-float
+      const float pl = __builtin_fmaf(sh, sh, -ph) + 2.0f * sh * sl;
+      const float th = qh + ph;
+      const float tb = th - qh;
+      ql += ((qh - (th - tb)) + (ph - tb)) + pl;
+      qh = th;
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off *= 2) {                // the other lane groups' coordinates
+      const float oh = __shfl_xor(qh, off), ol = __shfl_xor(ql, off);
+      const float th = qh + oh;
+      const float tb = th - qh;
+      ql = ((qh - (th - tb)) + (oh - tb)) + (ql + ol);
+      qh = th;
+    }
+    bad = bad || !(qh < qlim);
+    gram_parts_f(qh, ql, qinv, nq);
+    // head slots 4 g + j: the two coordinates' heads, then (group 0) Q x alpha, (groups 1, 2) the two c2 heads
+    {
+      const float sc = scale_of(gram_head_slot(0));          // kind 1, p = q = 0: the same weight in every group
+      const float f2 = g == 0 ? nq[0] * scale_of(gram_head_slot(2))
+                              : (g == 1 ? scale_of(gram_head_slot(4 + 2)) : (g == 2 ? scale_of(gram_head_slot(8 + 2)) : 0.0f));
+      bhd[t][0] = (_Float16)(nx[0][0] * sc);
+      bhd[t][1] = (_Float16)(nx[1][0] * sc);
+      bhd[t][2] = (_Float16)f2;
+      bhd[t][3] = (_Float16)0.0f;
+    }
+    // tail slots 32 hf + 8 g + j: j < 5 the combinations of coordinate 2 g + hf; j >= 5: group 0 the Q x alpha combinations and
+    // the third c2 part, group 1 (hf = 0, j = 5) the fourth
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const GramSlot sl = gram_tail_slot(32 * hf + j);     // group 0's entry: p, q and the weight do not depend on the group
+        btl[t][hf][j] = (_Float16)(nx[hf][sl.p] * scale_of(sl));
       }
-      bad = bad || !(qh < qlim);
-      gram_parts_f(qh, ql, qinv, nq);
-      auto xval = [&](const GramSlot sl) -> float {
-        if (sl.kind == 0) return 0.0f;
-        const float sc = __builtin_ldexpf(1.0f, gram_ax(gram_T(hx, sl)));
-        return sl.kind == 1 ? nx[sl.dim][sl.p] * sc : (sl.kind == 2 ? nq[sl.p] * sc : sc);
-      };
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v0 = xval(gram_head_slot(j)), v1 = xval(gram_head_slot(4 + j)), v2 = xval(gram_head_slot(8 + j)),
-                    v3 = xval(gram_head_slot(12 + j));
-        bhd[t][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
+      for (int j = 5; j < 8; ++j) {
+        const GramSlot s0 = gram_tail_slot(32 * hf + j), s1 = gram_tail_slot(32 * hf + 8 + j);
+        const float v0 = s0.kind == 2 ? nq[s0.p] * scale_of(s0) : scale_of(s0);      // kind 3 / empty: the weight itself / 0
+        const float v1 = scale_of(s1);                                                // kind 3 or empty
+        btl[t][hf][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : 0.0f));
       }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v0 = xval(gram_tail_slot(32 * hf + j)), v1 = xval(gram_tail_slot(32 * hf + 8 + j)),
-                      v2 = xval(gram_tail_slot(32 * hf + 16 + j)), v3 = xval(gram_tail_slot(32 * hf + 24 + j));
-          btl[t][hf][j] = (_Float16)(g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3)));
-        }
     }
   }
   return bad;
 }
+// the tables say what the code above assumes
+static_assert(gram_head_slot(0).kind == 1 && gram_head_slot(4 * 3 + 1).dim == 7 && gram_head_slot(2).kind == 2 && gram_head_slot(6).kind == 3 &&
+              gram_head_slot(10).kind == 3 && gram_head_slot(10).p == 1 && gram_head_slot(14).kind == 0 && gram_head_slot(3).kind == 0, "head slots");
+static_assert(gram_tail_slot(32 + 8 * 2 + 4).kind == 1 && gram_tail_slot(32 + 8 * 2 + 4).dim == 5 && gram_tail_slot(5).kind == 2 &&
+              gram_tail_slot(32 + 6).kind == 2 && gram_tail_slot(32 + 7).kind == 3 && gram_tail_slot(32 + 7).p == 2 && gram_tail_slot(8 + 5).kind == 3 &&
+              gram_tail_slot(8 + 5).p == 3 && gram_tail_slot(8 + 6).kind == 0 && gram_tail_slot(16 + 5).kind == 0 && gram_tail_slot(32 + 8 + 5).kind == 0, "tail slots");
 
 // the argument of the transcendental for the 2 x 2 tiles (query tile t, centre tile ct) of the chunk image at `buf`: head sum
 // (exact), then the tails
