@@ -82,12 +82,13 @@ typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 // conversion itself (the leading 11 bits of P wherever P is a normal f16 number), lo = 2^11 (P - hi) as one v_fma_mix_f32
 // that reads hi as the f16 number it is: fma(hi, -2^11, 2^11 P) is exact (every term a multiple of the last bit of P).
 // (v_pk_add_f32 / v_pk_mul_f32 for the subtraction and the gain: measured slower -- packed f32 VALU costs more than the two
-// plain instructions it replaces, MI355X_MICROARCH.md constants table.)
+// plain instructions it replaces, MI355X_MICROARCH.md constants table.  v_fma_mixlo_f16 + v_fma_mixhi_f16 writing the two halves of
+// the lo pair directly -- 2 instructions instead of 3 -- measured 5 % SLOWER at config 2: 92.1 vs 87.4 us, profiles/r03_gram_experiments.txt.)
 __device__ __forceinline__ void split_pair_mix(float p0, float p1, unsigned& hi, unsigned& lo) {
   hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
   const float q0 = p0 * kLoGain, q1 = p1 * kLoGain;
-  float d0, d1;
   const float ng = -kLoGain;
+  float d0, d1;
   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "s"(ng), "v"(q0));
   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "s"(ng), "v"(q1));
   lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
