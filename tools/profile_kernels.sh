@@ -15,7 +15,8 @@ run() {   # what B
   echo "ok $1 $2"
 }
 for w in fwd_cfg2; do run $w 65536 || exit 1; done
-for w in vjp_cfg3; do run $w 65536 || exit 1; done
+for w in vjp_cfg3 train_cfg3; do run $w 65536 || exit 1; done
+run train_1region 80000 || exit 1
 for w in fwd_cfg4_wide tick_cfg4; do run $w 32768 || exit 1; run $w 262144 || exit 1; done
 for m in st_ks st_select fullint frenet; do run roll_$m 262144 || exit 1; run roll_$m 32768 || exit 1; done
 for m in st_ks fullint frenet; do run rollvjp_$m 262144 || exit 1; run rollvjp_$m 32768 || exit 1; done
