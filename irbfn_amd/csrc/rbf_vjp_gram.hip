@@ -33,6 +33,7 @@ constexpr int kVgDist = 2 * (512 + 2 * 1024);            // per half: head [lane
 constexpr int kVgGA = 1024 + 2048;                       // hbar A operands: [s][lane] 8 B (hi, k = 16) + [s][lane] 16 B ((lo | hi), k = 32)
 constexpr int kVgBlock = kVgDist + kVgGA + 2 * 2048;     // + gT [part][lane] 16 B, xB [part][lane] 16 B = 12 KiB
 constexpr int kVgPieces = kVgBlock / 1024;
+constexpr int kVgOC = 10;                                // up to this many outputs hbar is ONE 16x16x32 MFMA (3 x 10 <= 32 slots)
 
 __device__ __forceinline__ float vg_pow2_ceil_scale(float mx) {
   if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;          // zero / Inf / NaN: unscaled
@@ -128,12 +129,16 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int o = 8 * (g & 1) + j;
+      // O <= kVgOC: ONE operand, k = 8 g + j: [0, 10) hi of output k, [10, 20) lo of output k - 10, [20, 30) hi of output k - 20 --
+      // hi x hi + lo x hi + hi x lo as one MFMA against (W hi | 2^-11 W hi | 2^-11 W lo); else A2 as described above
+      const int k = 8 * g + j;
+      const int o = O <= kVgOC ? (k < 30 ? k % 10 : 16) : 8 * (g & 1) + j;
+      const bool want_lo = O <= kVgOC ? (k >= 10 && k < 20) : g < 2;
       float v = 0.0f;
       if (q < B && o < O) v = gq * gout[q * O + o] * (oscale[o] / sh);
       _Float16 h, l;
       split_static_f16(v, h, l);
-      mix[j] = g < 2 ? l : h;
+      mix[j] = want_lo ? l : h;
     }
     gA1[s * 64 + lane] = hi;
     gA2[s * 64 + lane] = mix;
@@ -183,10 +188,16 @@ struct VjpGArgs {
 };
 
 #ifndef IRBFN_K2G_WAVES
-#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs.  (4 -- 128 VGPRs, 9 spilled -- measured 3 % faster and
-                                // WRONG: non-finite gradients; not pursued)
+#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs (O > 10), 129 (O <= 10).  4 -- 128 VGPRs with 9 spilled
+                                // before hbar became one MFMA, 126 without a spill since -- is 6 % faster (config 3: 174 vs 184 us) and WRONG, twice:
+                                // the gradients of every centre 16..31 (mod 32) non-finite, the others off by O(1), deterministically, at any batch size.
+                                // Excluded: the transcendentals reading MFMA results too early (an out-of-place form behind an explicit s_nop 7
+                                // fails the same way), spills, residency (fails at B = 2048).  Cause not found; the build stays at 3.
 #endif
-template <int DC, int BC>
+// OC: O <= kVgOC -- hbar's three products (hi x hi, lo x hi, hi x lo over <= 10 outputs: 30 of 32 slots) in ONE 16x16x32 MFMA; the
+// cross terms' B operands carry the 2^-11 of the (hi, lo) scheme, so nothing is left to combine on the VALU (28 instead of 32
+// MFMAs and 16 VALU instructions fewer per 32 x 32 pairs)
+template <int DC, int BC, bool OC>
 __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   if (*a.flag == a.gen) return;
@@ -233,11 +244,13 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int o = 8 * (g & 1) + j;
+        const int k = 8 * g + j;
+        const int o = OC ? (k < 30 ? k % 10 : 16) : 8 * (g & 1) + j;
         const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] : 0.0f;
         _Float16 h, l;
         split_static_f16(w, h, l);
-        wt2[ct][j] = g < 2 ? h : l;
+        if (OC) wt2[ct][j] = k < 10 ? h : (_Float16)((float)(k < 20 ? h : l) * kLoScale);    // exact (power of two) down to the subnormals
+        else wt2[ct][j] = g < 2 ? h : l;
       }
     }
   }
@@ -278,13 +291,18 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         f4_t hb[2], u[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wth[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);
-          const f4_t hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga2, wt2[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);   // lo x hi + hi x lo
+          f4_t hl = f4_t{0, 0, 0, 0};
+          if constexpr (OC) {
+            hb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga2, wt2[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);          // all three products
+          } else {
+            hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wth[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);
+            hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga2, wt2[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);              // lo x hi + hi x lo
+          }
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(qh, cbh[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);          // exact head sum
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt0, cbt[ct][0], u[ct], 0, 0, 0);
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt1, cbt[ct][1], u[ct], 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hb[ct][r] = __builtin_fmaf(hl[r], kLoScale, hb[ct][r]) * cE;
+          for (int r = 0; r < 4; ++r) hb[ct][r] = OC ? hb[ct][r] * cE : __builtin_fmaf(hl[r], kLoScale, hb[ct][r]) * cE;
         }
         float t8[8];
 #pragma unroll
@@ -391,9 +409,15 @@ size_t vjpg_block_bytes() { return kVgBlock; }
 template <int DC>
 static int launch_vjpg_dc(const VjpGArgs& a, int bc, dim3 grid, size_t lds, hipStream_t s) {
   switch (bc) {
-    case BC_GAUSS: hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_GAUSS>), grid, dim3(256), lds, s, a); break;
-    case BC_IQ: hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IQ>), grid, dim3(256), lds, s, a); break;
-    case BC_IMQ: hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IMQ>), grid, dim3(256), lds, s, a); break;
+    case BC_GAUSS: if (a.O <= kVgOC) hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_GAUSS, true>), grid, dim3(256), lds, s, a);
+                   else hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_GAUSS, false>), grid, dim3(256), lds, s, a);
+                   break;
+    case BC_IQ: if (a.O <= kVgOC) hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IQ, true>), grid, dim3(256), lds, s, a);
+                else hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IQ, false>), grid, dim3(256), lds, s, a);
+                break;
+    case BC_IMQ: if (a.O <= kVgOC) hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IMQ, true>), grid, dim3(256), lds, s, a);
+                 else hipLaunchKernelGGL((rbf_vjp_f16gram<DC, BC_IMQ, false>), grid, dim3(256), lds, s, a);
+                 break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());

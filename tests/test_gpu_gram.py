@@ -382,6 +382,16 @@ def _vjp_case(case, rng):
         B = 2500
         x = rng.uniform(lo - 0.02, hi + 0.02, size=(B, 7)).astype(np.float32)
         g = rng.normal(size=(B, 10)).astype(np.float32)
+    elif case == "iq_o16":
+        D, K, O = 7, 300, 16                                                 # more than 10 outputs: hbar as two MFMAs (A1 + A2)
+        cfg = _card(D, K, O, "inverse_quadratic", [-1.0] * D, [2.0] * D)
+        P = {"params": {"rbf_list": {"centers": rng.uniform(-1.5, 2.5, size=(1, K, D)).astype(np.float32),
+                                     "log_sigs": rng.uniform(-0.3, 0.8, size=(1, K)).astype(np.float32)},
+                        "linear": {"kernel": (rng.normal(size=(K, O)) * 10.0 ** rng.uniform(-2, 1, size=(1, O))).astype(np.float32),
+                                   "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+        B = 2500
+        x = rng.uniform(-1.1, 2.1, size=(B, D)).astype(np.float32)
+        g = rng.normal(size=(B, O)).astype(np.float32)
     elif case == "gauss_d8":
         D, K, O = 8, 200, 2                                                  # the Frenet planners' width
         cfg = _card(D, K, O, "gaussian", [-1.0] * D, [2.0] * D)
@@ -405,7 +415,7 @@ def _vjp_case(case, rng):
     return cfg, P, x, g
 
 
-@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "gauss_ckpt", "imq_d3", "gauss_d8"])
+@pytest.mark.parametrize("case", ["cfg3", "iq_ckpt", "gauss_ckpt", "imq_d3", "gauss_d8", "iq_o16"])
 def test_vjp_gram_matches_valu_kernel_and_oracle(gpu, case):
     import torch
     cfg, P, x, g = _vjp_case(case, np.random.default_rng(11))
