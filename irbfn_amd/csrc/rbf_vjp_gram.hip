@@ -192,7 +192,8 @@ struct VjpGArgs {
                                 // before hbar became one MFMA, 126 without a spill since -- is 6 % faster (config 3: 174 vs 184 us) and WRONG, twice:
                                 // the gradients of every centre 16..31 (mod 32) non-finite, the others off by O(1), deterministically, at any batch size.
                                 // Excluded: the transcendentals reading MFMA results too early (an out-of-place form behind an explicit s_nop 7
-                                // fails the same way), spills, residency (fails at B = 2048).  Cause not found; the build stays at 3.
+                                // fails the same way), spills, residency (fails at B = 2048), MFMA destinations overlapping their sources (the allocator produces them in both
+                                // builds; tools/probe_mfma_overlap.hip: fine on the hardware).  Cause not found; the build stays at 3.
 #endif
 // OC: O <= kVgOC -- hbar's three products (hi x hi, lo x hi, hi x lo over <= 10 outputs: 30 of 32 slots) in ONE 16x16x32 MFMA; the
 // cross terms' B operands carry the 2^-11 of the (hi, lo) scheme, so nothing is left to combine on the VALU (28 instead of 32
