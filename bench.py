@@ -225,7 +225,7 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_fingerprint(names=("rbf_forward_gram.hip", "rbf_forward_f16_narrow.h", "rbf_forward_f16.hip", "rbf_forward_f16_wide.h", "f16_split.h",
+def kernel_fingerprint(names=("rbf_forward_gram.hip", "rbf_forward_gram.h", "pack_all.hip", "rbf_forward_f16_narrow.h", "rbf_forward_f16.hip", "rbf_forward_f16_wide.h", "f16_split.h",
                               "rbf_forward.h", "rbf_forward.hip")) -> str:
     """Hash of the sources the headline kernel is built from: profiles/*_traffic.json is only trusted for the
     code it was measured on (tools/measure_traffic.py stamps it)."""

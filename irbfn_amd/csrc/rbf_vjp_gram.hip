@@ -345,6 +345,11 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         const h8_t bl = __builtin_bit_cast(h8_t, u4_t{pl[0], pl[1], pl[2], pl[3]});
         const h8_t ah = __builtin_bit_cast(h8_t, u4_t{th[0], th[1], th[2], th[3]});
         const h8_t al = __builtin_bit_cast(h8_t, u4_t{tl[0], tl[1], tl[2], tl[3]});
+        // (Measured and NOT taken: lo = p - hi without the 2^11 gain -- 4 instead of 6 instructions per pair, its products in the
+        // hi x hi accumulators; a gradient is judged against its leaf's largest entry, so the f16 subnormals' 2^-25 absolute would do.
+        // Config 3: 171-180 instead of 182-187 us with the same errors -- and the inverse-quadratic instance returned run-dependent
+        // garbage in every leaf, d log_sigs included, which never sees those operands: the same allocation-sensitive failure as the
+        // 4-waves build, see IRBFN_K2G_WAVES.)
         dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dWl[ct], 0, 0, 0);
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dWl[ct], 0, 0, 0);
