@@ -171,6 +171,16 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
 }
 
 // ---- main kernel -------------------------------------------------------------------------------------------
+#ifdef IRBFN_K2G_PLAIN_SPLIT   // experiment (tools/build_variant.py): see the note at the dW / dC products
+__device__ __forceinline__ void split_pair_plain(float p0, float p1, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+  float d0, d1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(p0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(p1));
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+}
+#endif
+
 struct VjpGArgs {
   const unsigned char* __restrict__ qblk;   // [nqb][kVgBlock]
   const float* __restrict__ scales;         // [0] = s_g, [1] = s_h
@@ -189,8 +199,8 @@ struct VjpGArgs {
 
 #ifndef IRBFN_K2G_WAVES
 #define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs (O > 10), 129 (O <= 10).  4 -- 128 VGPRs with 9 spilled
-                                // before hbar became one MFMA, 126 without a spill since -- is 6 % faster (config 3: 174 vs 184 us) and WRONG, twice:
-                                // the gradients of every centre 16..31 (mod 32) non-finite, the others off by O(1), deterministically, at any batch size.
+                                // before hbar became one MFMA, 126 without a spill since -- is 6 % faster (config 3: 174 vs 184 us) and WRONG, twice, in
+                                // ALL 24 instances: the gradients of every centre 16..31 (mod 32) non-finite, the others off by O(1), deterministically, at any batch size.
                                 // Excluded: the transcendentals reading MFMA results too early (an out-of-place form behind an explicit s_nop 7
                                 // fails the same way), spills, residency (fails at B = 2048), MFMA destinations overlapping their sources (the allocator produces them in both
                                 // builds; tools/probe_mfma_overlap.hip: fine on the hardware).  Cause not found; the build stays at 3.
@@ -338,8 +348,13 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         unsigned ph[4], pl[4], th[4], tl[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
+#ifdef IRBFN_K2G_PLAIN_SPLIT
+          split_pair_plain(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
+          split_pair_plain(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
+#else
           split_pair_mix(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
           split_pair_mix(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
+#endif
         }
         const h8_t bh = __builtin_bit_cast(h8_t, u4_t{ph[0], ph[1], ph[2], ph[3]});
         const h8_t bl = __builtin_bit_cast(h8_t, u4_t{pl[0], pl[1], pl[2], pl[3]});
@@ -347,15 +362,25 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         const h8_t al = __builtin_bit_cast(h8_t, u4_t{tl[0], tl[1], tl[2], tl[3]});
         // (Measured and NOT taken: lo = p - hi without the 2^11 gain -- 4 instead of 6 instructions per pair, its products in the
         // hi x hi accumulators; a gradient is judged against its leaf's largest entry, so the f16 subnormals' 2^-25 absolute would do.
-        // Config 3: 171-180 instead of 182-187 us with the same errors -- and the inverse-quadratic instance returned run-dependent
-        // garbage in every leaf, d log_sigs included, which never sees those operands: the same allocation-sensitive failure as the
-        // 4-waves build, see IRBFN_K2G_WAVES.)
+        // Config 3: 171-180 instead of 182-187 us with the same errors -- and the four inverse-quadratic instances with hbar as one
+        // MFMA (O <= 10; any D) return run-dependent garbage in every leaf, d log_sigs included, which never sees those operands;
+        // the other 20 instances pass (tests/test_gpu_gram.py::test_vjp_gram_every_instance...).  Kept behind IRBFN_K2G_PLAIN_SPLIT
+        // for tools/build_variant.py; see also IRBFN_K2G_WAVES.)
+#ifdef IRBFN_K2G_PLAIN_SPLIT
+        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
+        dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dWl[ct], 0, 0, 0);
+        dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbh, dC[ct], 0, 0, 0);
+        dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbl, dCl[ct], 0, 0, 0);
+        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dW[ct], 0, 0, 0);
+        dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xbh, dC[ct], 0, 0, 0);
+#else
         dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dWl[ct], 0, 0, 0);
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dWl[ct], 0, 0, 0);
         dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbh, dC[ct], 0, 0, 0);
         dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xbh, dCl[ct], 0, 0, 0);
         dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbl, dCl[ct], 0, 0, 0);
+#endif
       }
     }
     step_barrier();                                          // block i + 2 is there; everybody has left block i

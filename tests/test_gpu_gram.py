@@ -437,6 +437,39 @@ def test_vjp_gram_matches_valu_kernel_and_oracle(gpu, case):
         assert ea <= max(2e-5, 2.0 * eb), (case, grp, name, ea, eb)
 
 
+@pytest.mark.parametrize("O", [5, 16])
+@pytest.mark.parametrize("basis", ["gaussian", "inverse_quadratic", "inverse_multiquadric"])
+@pytest.mark.parametrize("D", [3, 4, 7, 8])
+def test_vjp_gram_every_instance_is_deterministic_and_agrees_with_the_float32_kernel(gpu, D, basis, O):
+    """Every compiled instance of K2g (4 widths x 3 basis classes x hbar as one / two MFMAs): bit-identical run to run and equal
+    to the all-float32 K2 to 2e-5 of each leaf's largest entry.  (Two faster variants of this kernel return garbage here: built for
+    four waves per SIMD, all 24 instances; with the operand split without its gain, the four inverse-quadratic instances with hbar as
+    one MFMA, run-dependent -- while the narrower case list above passed all but one of them: DESIGN section 4, K2g.)"""
+    import torch
+    rng = np.random.default_rng(100 * D + O)
+    K, B = 200, 2100
+    cfg = _card(D, K, O, basis, [-1.0] * D, [2.0] * D)
+    P = {"params": {"rbf_list": {"centers": rng.uniform(-1.4, 2.4, size=(1, K, D)).astype(np.float32),
+                                 "log_sigs": rng.uniform(-0.2, 0.9, size=(1, K)).astype(np.float32)},
+                    "linear": {"kernel": rng.normal(size=(K, O)).astype(np.float32), "bias": rng.normal(size=(O,)).astype(np.float32)}}}
+    x = torch.from_numpy(rng.uniform(-1.05, 2.05, size=(B, D)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.normal(size=(B, O)).astype(np.float32)).cuda()
+    net = WCRBFNet.from_config(cfg)
+    net.set_options(vjp_kernel=_lib.VJP_K2G)
+    runs = [net.vjp(P, x, g)["params"] for _ in range(3)]
+    assert net.last_launch()["kernel"].startswith("rbf_vjp_f16gram<"), net.last_launch()
+    net.set_options(vjp_kernel=_lib.VJP_K2)
+    ref = net.vjp(P, x, g)["params"]
+    net.set_options(vjp_kernel=_lib.VJP_AUTO)
+    for grp, name in LEAVES:
+        a0 = runs[0][grp][name]
+        assert torch.isfinite(a0).all(), (D, basis, O, name)
+        assert torch.equal(a0, runs[1][grp][name]) and torch.equal(a0, runs[2][grp][name]), (D, basis, O, name)
+        r = ref[grp][name]
+        err = float((a0 - r).abs().max() / (r.abs().max() + 1e-30))
+        assert err <= 2e-5, (D, basis, O, name, err)
+
+
 def test_vjp_gram_hands_over_when_a_query_leaves_the_box(gpu):
     """A query outside the representable box of the expansion raises the pre-pass's flag: K2g returns at once and K2h, launched
     behind it, computes the slabs -- the gradients are right either way (here against the float64 restatement)."""
