@@ -93,7 +93,7 @@ int irbfn_net_destroy(irbfn_net* net);
 
 /* Binds the parameter pytree {"rbf_list": {"centers"[R,K,D], "log_sigs"[R,K]},
  * "linear": {"kernel"[K,O], "bias"[O]}} (checkpoint layout).  Device pointers; the
- * data is re-packed on `stream` into the descriptor's own record buffers (a few small kernels), so the
+ * data is re-packed on `stream` into the descriptor's own images (two launches, pack_all.hip), so the
  * caller may overwrite its arrays afterwards.  Call again after every optimiser step.  For nets the
  * matrix-core kernels K1g / K2g can take (one region, d <= 8, fast basis) the call ends with ONE small
  * synchronous read-back on `stream` (64 bytes: do the bound parameters fit K1g's expansion?) -- the
