@@ -320,7 +320,12 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) t8[ct * 4 + r] = u[ct][r];
+#ifdef IRBFN_K2G_NOASM_TRANS                                   // diagnosis: the transcendentals as builtins, no inline asm
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t8[q] = BC == BC_GAUSS ? __builtin_amdgcn_exp2f(t8[q]) : (BC == BC_IQ ? __builtin_amdgcn_rcpf(t8[q]) : __builtin_amdgcn_rsqf(t8[q]));
+#else
         trans_block<BC, 8>(t8);                              // P = PS phi
+#endif
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -351,6 +356,9 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
 #ifdef IRBFN_K2G_PLAIN_SPLIT
           split_pair_plain(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
           split_pair_plain(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
+#elif defined(IRBFN_K2G_NOASM_SPLIT)                           // diagnosis: the (hi, lo) split in plain C++ (f16_split.h), no inline asm
+          split_pair_f16<3>(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
+          split_pair_f16<3>(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
 #else
           split_pair_mix(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
           split_pair_mix(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
