@@ -140,7 +140,6 @@ int irbfn_net_set_params(irbfn_net* net, const float* centers_dev, const float* 
                          const float* kernel_dev, const float* bias_dev, void* stream) {
   if (!net || !centers_dev || !log_sigs_dev || !kernel_dev || !bias_dev) return IRBFN_ERR_BAD_ARG;
   int rc = launch_pack_all(net, centers_dev, log_sigs_dev, kernel_dev, bias_dev, as_stream(stream));
-  if (rc == IRBFN_OK && net->sp_ok) rc = launch_pack_sparse(net, centers_dev, log_sigs_dev, kernel_dev, as_stream(stream));
   if (rc == IRBFN_OK) net->has_params = true;
   return rc;
 }

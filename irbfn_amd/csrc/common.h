@@ -175,7 +175,7 @@ int padded_O(int O);
 int sparse_setup(irbfn_net* net, const float* lo, const float* hi, const float* delta, const int* dim_ranges);
 void sparse_free(irbfn_net* net);
 bool sparse_preferred(const irbfn_net* net, int64_t B);
-int launch_pack_sparse(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s);
+void sparse_pack_tables(const irbfn_net* net, float** ctab, float** wtab, int* wp);   // K1r / K2r tables packed by pack_all.hip (role P)
 bool sparse_vjp_eligible(const irbfn_net* net);
 int sparse_vjp_slices(const irbfn_net* net, int64_t B);
 size_t sparse_vjp_workspace_bytes(const irbfn_net* net, int64_t B);

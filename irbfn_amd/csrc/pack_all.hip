@@ -8,6 +8,7 @@
 //     M  records of K1m                                 one thread per centre
 //     C  power-of-two column scales of W (K1h / K1g)    one block per output column
 //     S  K1g statistics, partial: per block of 1024 centres the per-coordinate max and -min, the largest |alpha|, finiteness
+//     P  the centre and weight tables of the region-sparse kernels K1r / K2r (rbf_sparse.hip)
 //   level 1 (needs C and S), roles by block range:
 //     F  K1h chunk images                               one thread per centre
 //     G  K1g chunk images                               one block per chunk of 32 centres: every block folds the partial statistics
@@ -44,7 +45,10 @@ struct PackArgs {
   float gscale;
   int CW, OW;                                                // K1m record: centre words, weight words
   int RF, NT, nchunks;                                       // K1h / K1g chunk images
-  int nbR, nbM, nbC, nbS, nbF, nbG;
+  int nbR, nbM, nbC, nbS, nbP, nbF, nbG;
+  float* __restrict__ sp_ctab;                               // K1r / K2r: [n_ranges][RS] centre table, [K][WP] weight rows
+  float* __restrict__ sp_wtab;
+  int sp_nr, sp_EW, sp_RS, sp_WP;
 };
 
 // ---- level 0 ---------------------------------------------------------------------------------------------
@@ -156,6 +160,27 @@ __device__ __forceinline__ void stats_body(const PackArgs& a, int vb, float (&re
   if (threadIdx.x < kStatsVals) a.part[(size_t)vb * kStatsVals + threadIdx.x] = m;
 }
 
+// ctab[r][k] = { c[0..DC), folded width scale (as rec[DC] of the dense kernels), 0.. }, a zero padding slot behind each region's K
+// entries; wtab[k] = W[k, 0..WP)
+__device__ __forceinline__ void sparse_tables_body(const PackArgs& a, int vb) {
+  const int n = vb * kPackBlock + threadIdx.x;
+  if (n < a.K * a.sp_WP) {
+    const int k = n / a.sp_WP, o = n - k * a.sp_WP;
+    a.sp_wtab[n] = o < a.O ? a.kernel[(size_t)k * a.O + o] : 0.0f;
+  }
+  const int pad = a.sp_RS - a.K * a.sp_EW;
+  if (n < a.sp_nr * pad) {
+    const int r = n / pad, j = n - r * pad;
+    a.sp_ctab[(size_t)r * a.sp_RS + a.K * a.sp_EW + j] = 0.0f;
+  }
+  if (n >= a.sp_nr * a.K) return;
+  const int r = n / a.K, k = n - r * a.K;
+  float* dst = a.sp_ctab + (size_t)r * a.sp_RS + (size_t)k * a.sp_EW;
+  for (int j = 0; j < a.sp_EW; ++j) dst[j] = (j < a.D) ? a.centers[(size_t)n * a.D + j] : 0.0f;
+  const float s2 = expf(-2.0f * a.log_sigs[n]);
+  dst[a.DC] = a.bclass == BC_GAUSS ? -a.gscale * 1.4426950408889634f * s2 : s2;
+}
+
 __global__ __launch_bounds__(kPackBlock) void pack_level0_kernel(const PackArgs a) {
   __shared__ float red[kPackBlock / 64][kStatsVals];
   int vb = blockIdx.x;
@@ -165,7 +190,9 @@ __global__ __launch_bounds__(kPackBlock) void pack_level0_kernel(const PackArgs 
   vb -= a.nbM;
   if (vb < a.nbC) { colscale_body(a, vb, red); return; }
   vb -= a.nbC;
-  if (vb < a.nbS) stats_body(a, vb, red);
+  if (vb < a.nbS) { stats_body(a, vb, red); return; }
+  vb -= a.nbS;
+  if (vb < a.nbP) sparse_tables_body(a, vb);
 }
 
 // ---- level 1 ---------------------------------------------------------------------------------------------
@@ -405,7 +432,18 @@ int launch_pack_all(irbfn_net* net, const float* centers, const float* log_sigs,
   a.nbS = gram ? (net->N + kStatsCentres - 1) / kStatsCentres : 0;
   a.nbF = net->f16_img ? (a.nchunks * kF16Chunk + kPackBlock - 1) / kPackBlock : 0;
   a.nbG = gram ? a.nchunks : 0;
-  hipLaunchKernelGGL(pack_level0_kernel, dim3(a.nbR + a.nbM + a.nbC + a.nbS), dim3(kPackBlock), 0, s, a);
+  a.nbP = 0;
+  if (net->sp_ok) {
+    float *ctab = nullptr, *wtab = nullptr;
+    sparse_pack_tables(net, &ctab, &wtab, &a.sp_WP);
+    a.sp_ctab = ctab; a.sp_wtab = wtab;
+    a.sp_nr = net->n_ranges; a.sp_EW = net->sp_EW; a.sp_RS = net->sp_RS;
+    int np = a.sp_nr * net->K > net->K * a.sp_WP ? a.sp_nr * net->K : net->K * a.sp_WP;
+    const int npad = a.sp_nr * (a.sp_RS - net->K * a.sp_EW);
+    np = np > npad ? np : npad;
+    a.nbP = (np + kPackBlock - 1) / kPackBlock;
+  }
+  hipLaunchKernelGGL(pack_level0_kernel, dim3(a.nbR + a.nbM + a.nbC + a.nbS + a.nbP), dim3(kPackBlock), 0, s, a);
   IRBFN_HIP_CHECK(hipGetLastError());
   if (a.nbF + a.nbG > 0) {
     hipLaunchKernelGGL(pack_level1_kernel, dim3(a.nbF + a.nbG), dim3(kPackBlock), 0, s, a);

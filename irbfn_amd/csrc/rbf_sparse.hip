@@ -190,40 +190,14 @@ bool sparse_preferred(const irbfn_net* net, int64_t B) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pack (once per parameter upload): ctab[r][k] = { c[0..DC), folded width scale, 0.. }, wtab[k] = W[k, 0..OPS)
+// pack (once per parameter upload): ctab[r][k] = { c[0..DC), folded width scale, 0.. }, wtab[k] = W[k, 0..kSpWP) -- a role of the
+// first pack launch (pack_all.hip, role P); here only where the tables live
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sparse_pack_kernel(const float* __restrict__ centers, const float* __restrict__ log_sigs,
-                                                          const float* __restrict__ kernel, float* __restrict__ ctab,
-                                                          float* __restrict__ wtab, int nr, int K, int D, int DC, int EW, int RS,
-                                                          int O, int OPS, int bclass, float gscale) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n < K * kSpWP) {
-    const int k = n / kSpWP, o = n - k * kSpWP;
-    wtab[n] = o < O ? kernel[(size_t)k * O + o] : 0.0f;
-  }
-  if (n < nr * (RS - K * EW)) {                 // the padding slot behind each region's K entries
-    const int pad = RS - K * EW, r = n / pad, j = n - r * pad;
-    ctab[(size_t)r * RS + K * EW + j] = 0.0f;
-  }
-  if (n >= nr * K) return;
-  const int r = n / K, k = n - r * K;
-  float* dst = ctab + (size_t)r * RS + (size_t)k * EW;
-  for (int j = 0; j < EW; ++j) dst[j] = (j < D) ? centers[(size_t)n * D + j] : 0.0f;
-  const float s2 = expf(-2.0f * log_sigs[n]);
-  dst[DC] = bclass == BC_GAUSS ? -gscale * 1.4426950408889634f * s2 : s2;      // as rec[DC] of the dense kernels
-}
-
-int launch_pack_sparse(irbfn_net* net, const float* centers, const float* log_sigs, const float* kernel, hipStream_t s) {
-  if (!net->sp_ok) return IRBFN_OK;
-  const int nr = net->n_ranges;
-  int n = std::max(nr * net->K, net->K * kSpWP);
-  n = std::max(n, nr * (net->sp_RS - net->K * net->sp_EW));
-  const SpImg im = sp_img_layout(nr, net->sp_RS, net->sp_E, net->K);
-  hipLaunchKernelGGL(sparse_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centers, log_sigs, kernel, net->sp_img + im.ctab,
-                     net->sp_img + im.wtab, nr, net->K, net->D, net->DC, net->sp_EW, net->sp_RS, net->O, net->sp_OPS, net->bclass,
-                     gauss_scale(net->basis));
-  IRBFN_HIP_CHECK(hipGetLastError());
-  return IRBFN_OK;
+void sparse_pack_tables(const irbfn_net* net, float** ctab, float** wtab, int* wp) {
+  const SpImg im = sp_img_layout(net->n_ranges, net->sp_RS, net->sp_E, net->K);
+  *ctab = net->sp_img + im.ctab;
+  *wtab = net->sp_img + im.wtab;
+  *wp = kSpWP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
