@@ -21,7 +21,7 @@
 //  * the 42 tail products (each < 2^-10 of a head product) are added to S1 by two 16x16x32 MFMAs: truncation there is
 //    2^-24 of max(|u|, 2^-10 M).
 // So u carries the error of a float32 evaluation of the direct form (a few 2^-24 |u|), not 2^-24 M.  Exponents EX .. E2 are
-// chosen per net from the centres (gram_stats_kernel); a query outside the representable box (|x'_i| >= 2^EX, non-finite)
+// chosen per net from the centres (pack_all.hip: statistics role, header per block); a query outside the representable box (|x'_i| >= 2^EX, non-finite)
 // makes its WAVE take the VALU distances of K1h for its 32 queries (same records, same f16_arg): results there are K1h's.
 // A net whose exponents do not fit (ok = 0 in the header, read back once by irbfn_net_set_params) is not dispatched here.
 //
