@@ -222,6 +222,25 @@ static_assert(gram_tail_slot(32 + 8 * 2 + 4).kind == 1 && gram_tail_slot(32 + 8 
               gram_tail_slot(32 + 6).kind == 2 && gram_tail_slot(32 + 7).kind == 3 && gram_tail_slot(32 + 7).p == 2 && gram_tail_slot(8 + 5).kind == 3 &&
               gram_tail_slot(8 + 5).p == 3 && gram_tail_slot(8 + 6).kind == 0 && gram_tail_slot(16 + 5).kind == 0 && gram_tail_slot(32 + 8 + 5).kind == 0, "tail slots");
 
+// The exact head sums u[t][ct] = A[ct] x B[t] (v_mfma_f32_16x16x16_f16, C = 0) of the 2 x 2 tiles, as ONE asm block that ends in
+// five wait states.  gfx950 does NOT interlock a 16x16x32 MFMA that accumulates onto the result of a 16x16x16 one, and hipcc does
+// not pad the pair: with fewer than 5 wait states (or one other MFMA) between the two the second reads a stale accumulator --
+// half of its outputs wrong, tools/probe_mfma_dependent.hip (16x16x32 -> 16x16x32, 16x16x16 -> 16x16x16 and MFMA -> VALU are
+// interlocked).  The compiler's schedule had kept the pairs apart in the shipped kernels and put them back to back in faster
+// variants of K2g (four waves per SIMD: all 24 instances wrong), which is how this was found.
+__device__ __forceinline__ void gram_heads(const h4_t (&a)[2], const h4_t (&b)[2], f4_t (&u)[2][2]) {
+  asm("v_mfma_f32_16x16x16_f16 %0, %4, %6, 0\n v_mfma_f32_16x16x16_f16 %1, %5, %6, 0\n v_mfma_f32_16x16x16_f16 %2, %4, %7, 0\n "
+      "v_mfma_f32_16x16x16_f16 %3, %5, %7, 0\n s_nop 4"
+      : "=&v"(u[0][0]), "=&v"(u[0][1]), "=&v"(u[1][0]), "=&v"(u[1][1])
+      : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+}
+// the same for one query half against two centre tiles (K2g): u[ct] = A x B[ct]
+__device__ __forceinline__ void gram_heads2(const h4_t& a, const h4_t (&b)[2], f4_t (&u)[2]) {
+  asm("v_mfma_f32_16x16x16_f16 %0, %2, %3, 0\n v_mfma_f32_16x16x16_f16 %1, %2, %4, 0\n s_nop 4"
+      : "=&v"(u[0]), "=&v"(u[1])
+      : "v"(a), "v"(b[0]), "v"(b[1]));
+}
+
 // the argument of the transcendental for the 2 x 2 tiles (query tile t, centre tile ct) of the chunk image at `buf`: head sum
 // (exact), then the tails
 __device__ __forceinline__ void gram_distances(const unsigned char* buf, int lane, const h4_t (&bhd)[2], const h8_t (&btl)[2][2],
@@ -234,11 +253,7 @@ __device__ __forceinline__ void gram_distances(const unsigned char* buf, int lan
     atl[ct][0] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 0) * 1024 + lane * 16);
     atl[ct][1] = *reinterpret_cast<const h8_t*>(buf + kGramHeadBytes + (ct * 2 + 1) * 1024 + lane * 16);
   }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-      u[t][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahd[ct], bhd[t], f4_t{0, 0, 0, 0}, 0, 0, 0);   // exact head sum
+  gram_heads(ahd, bhd, u);                                     // exact head sums
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
 #pragma unroll

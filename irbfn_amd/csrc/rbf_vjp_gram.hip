@@ -171,7 +171,11 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
 }
 
 // ---- main kernel -------------------------------------------------------------------------------------------
-#ifdef IRBFN_K2G_PLAIN_SPLIT   // experiment (tools/build_variant.py): see the note at the dW / dC products
+// (hi, lo) of two values WITHOUT the 2^11 gain on lo: hi = the packed toward-zero conversion, lo = p - hi (one v_fma_mix_f32 that
+// reads hi as the f16 number it is: exact) converted as it is -- 4 instructions per pair instead of the 6 of split_pair_mix.
+// lo < 2^-10 |p| falls into the f16 subnormals for |p| < 2^-4 and is then good to 2^-25 ABSOLUTE only (the matrix cores honour
+// subnormal inputs): harmless here, where p <= 2^14..2^15 and a gradient is judged against the largest entry of its leaf (the
+// forward, judged per output, keeps the gain).  The products with an ungained lo carry the scale of hi x hi and share its accumulator.
 __device__ __forceinline__ void split_pair_plain(float p0, float p1, unsigned& hi, unsigned& lo) {
   hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
   float d0, d1;
@@ -179,7 +183,6 @@ __device__ __forceinline__ void split_pair_plain(float p0, float p1, unsigned& h
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(p1));
   lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
 }
-#endif
 
 struct VjpGArgs {
   const unsigned char* __restrict__ qblk;   // [nqb][kVgBlock]
@@ -198,12 +201,9 @@ struct VjpGArgs {
 };
 
 #ifndef IRBFN_K2G_WAVES
-#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs (O > 10), 129 (O <= 10).  4 -- 128 VGPRs with 9 spilled
-                                // before hbar became one MFMA, 126 without a spill since -- is 6 % faster (config 3: 174 vs 184 us) and WRONG, twice, in
-                                // ALL 24 instances: the gradients of every centre 16..31 (mod 32) non-finite, the others off by O(1), deterministically, at any batch size.
-                                // Excluded: the transcendentals reading MFMA results too early (an out-of-place form behind an explicit s_nop 7
-                                // fails the same way), spills, residency (fails at B = 2048), MFMA destinations overlapping their sources (the allocator produces them in both
-                                // builds; tools/probe_mfma_overlap.hip: fine on the hardware).  Cause not found; the build stays at 3.
+#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs (O > 10), 129 (O <= 10).  4 (126 VGPRs without a spill
+                                // where hbar is one MFMA) is worth 1.5 % at config 3 with 1024 blocks per launch and spills for O > 10: not taken.
+                                // (Until the head sums went out through gram_heads2 -- rbf_forward_gram.h -- every 4-waves build was WRONG.)
 #endif
 // OC: O <= kVgOC -- hbar's three products (hi x hi, lo x hi, hi x lo over <= 10 outputs: 30 of 32 slots) in ONE 16x16x32 MFMA; the
 // cross terms' B operands carry the 2^-11 of the (hi, lo) scheme, so nothing is left to combine on the VALU (28 instead of 32
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         const h4v gah = *reinterpret_cast<const h4v*>(cur + kVgDist + (s * 64 + lane) * 8);
         const h8_t ga2 = *reinterpret_cast<const h8_t*>(cur + kVgDist + 1024 + (s * 64 + lane) * 16);
         f4_t hb[2], u[2];
+        gram_heads2(qh, cbh, u);                             // exact head sums (rbf_forward_gram.h: why not the builtin)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           f4_t hl = f4_t{0, 0, 0, 0};
@@ -309,7 +310,6 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
             hb[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(gah, wth[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);
             hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga2, wt2[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);              // lo x hi + hi x lo
           }
-          u[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(qh, cbh[ct], f4_t{0, 0, 0, 0}, 0, 0, 0);          // exact head sum
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt0, cbt[ct][0], u[ct], 0, 0, 0);
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt1, cbt[ct][1], u[ct], 0, 0, 0);
 #pragma unroll
@@ -320,12 +320,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) t8[ct * 4 + r] = u[ct][r];
-#ifdef IRBFN_K2G_NOASM_TRANS                                   // diagnosis: the transcendentals as builtins, no inline asm
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t8[q] = BC == BC_GAUSS ? __builtin_amdgcn_exp2f(t8[q]) : (BC == BC_IQ ? __builtin_amdgcn_rcpf(t8[q]) : __builtin_amdgcn_rsqf(t8[q]));
-#else
         trans_block<BC, 8>(t8);                              // P = PS phi
-#endif
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -353,42 +348,21 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         unsigned ph[4], pl[4], th[4], tl[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-#ifdef IRBFN_K2G_PLAIN_SPLIT
           split_pair_plain(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
           split_pair_plain(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
-#elif defined(IRBFN_K2G_NOASM_SPLIT)                           // diagnosis: the (hi, lo) split in plain C++ (f16_split.h), no inline asm
-          split_pair_f16<3>(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
-          split_pair_f16<3>(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
-#else
-          split_pair_mix(hq[ct][2 * jj], hq[ct][2 * jj + 1], ph[jj], pl[jj]);
-          split_pair_mix(tq[ct][2 * jj], tq[ct][2 * jj + 1], th[jj], tl[jj]);
-#endif
         }
         const h8_t bh = __builtin_bit_cast(h8_t, u4_t{ph[0], ph[1], ph[2], ph[3]});
         const h8_t bl = __builtin_bit_cast(h8_t, u4_t{pl[0], pl[1], pl[2], pl[3]});
         const h8_t ah = __builtin_bit_cast(h8_t, u4_t{th[0], th[1], th[2], th[3]});
         const h8_t al = __builtin_bit_cast(h8_t, u4_t{tl[0], tl[1], tl[2], tl[3]});
-        // (Measured and NOT taken: lo = p - hi without the 2^11 gain -- 4 instead of 6 instructions per pair, its products in the
-        // hi x hi accumulators; a gradient is judged against its leaf's largest entry, so the f16 subnormals' 2^-25 absolute would do.
-        // Config 3: 171-180 instead of 182-187 us with the same errors -- and the four inverse-quadratic instances with hbar as one
-        // MFMA (O <= 10; any D) return run-dependent garbage in every leaf, d log_sigs included, which never sees those operands;
-        // the other 20 instances pass (tests/test_gpu_gram.py::test_vjp_gram_every_instance...).  Kept behind IRBFN_K2G_PLAIN_SPLIT
-        // for tools/build_variant.py; see also IRBFN_K2G_WAVES.)
-#ifdef IRBFN_K2G_PLAIN_SPLIT
+        // the lo halves of P and tts carry no gain (split_pair_plain): their products join the hi x hi accumulators; the pre-packed
+        // g lo and x' lo carry 2^11 and keep the second ones
         dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
         dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dWl[ct], 0, 0, 0);
         dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbh, dC[ct], 0, 0, 0);
         dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbl, dCl[ct], 0, 0, 0);
         dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dW[ct], 0, 0, 0);
         dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xbh, dC[ct], 0, 0, 0);
-#else
-        dW[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bh, dW[ct], 0, 0, 0);
-        dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtl, bh, dWl[ct], 0, 0, 0);
-        dWl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gth, bl, dWl[ct], 0, 0, 0);
-        dC[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbh, dC[ct], 0, 0, 0);
-        dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xbh, dCl[ct], 0, 0, 0);
-        dCl[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xbl, dCl[ct], 0, 0, 0);
-#endif
       }
     }
     step_barrier();                                          // block i + 2 is there; everybody has left block i
