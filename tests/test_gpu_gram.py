@@ -442,9 +442,9 @@ def test_vjp_gram_matches_valu_kernel_and_oracle(gpu, case):
 @pytest.mark.parametrize("D", [3, 4, 7, 8])
 def test_vjp_gram_every_instance_is_deterministic_and_agrees_with_the_float32_kernel(gpu, D, basis, O):
     """Every compiled instance of K2g (4 widths x 3 basis classes x hbar as one / two MFMAs): bit-identical run to run and equal
-    to the all-float32 K2 to 2e-5 of each leaf's largest entry.  (Two faster variants of this kernel return garbage here: built for
-    four waves per SIMD, all 24 instances; with the operand split without its gain, the four inverse-quadratic instances with hbar as
-    one MFMA, run-dependent -- while the narrower case list above passed all but one of them: DESIGN section 4, K2g.)"""
+    to the all-float32 K2 to 2e-5 of each leaf's largest entry.  (What found the MFMA hazard of DESIGN section 4, K2g: a 16x16x32
+    MFMA accumulating onto a 16x16x16 result is not interlocked on gfx950; two faster builds of this kernel returned garbage in 24 and
+    in 4 of these instances while the narrower case list above passed all but one of them.)"""
     import torch
     rng = np.random.default_rng(100 * D + O)
     K, B = 200, 2100
