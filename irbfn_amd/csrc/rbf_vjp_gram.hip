@@ -34,6 +34,13 @@ constexpr int kVgGA = 1024 + 2048;                       // hbar A operands: [s]
 constexpr int kVgBlock = kVgDist + kVgGA + 2 * 2048;     // + gT [part][lane] 16 B, xB [part][lane] 16 B = 12 KiB
 constexpr int kVgPieces = kVgBlock / 1024;
 constexpr int kVgOC = 10;                                // up to this many outputs hbar is ONE 16x16x32 MFMA (3 x 10 <= 32 slots)
+// hbar's operands carry 2^-33 of the factor 2^-ET between hbar and tt themselves: the cotangent side 2^-16 (|operand| <= 1/2), the
+// weight side 2^-17 (<= 1/4) on top of the 2^15 of split_static_f16 -- small entries sink into the f16 subnormals, which the
+// matrix cores honour: a (hi, lo) pair then keeps 2^-36 ABSOLUTE against operands of size 2^-2, beyond float32.  The gaussian
+// (ET = 33) needs no multiplication of hbar at all any more, the other bases one by 2^-(ET - 33).
+constexpr int kVgExpA = 16, kVgExpB = 17;
+constexpr float kVgCrossA = 1.0f / 32.0f, kVgCrossB = 1.0f / 64.0f;      // kVgCrossA * kVgCrossB = kLoScale (2^-11)
+static_assert(kVgCrossA * kVgCrossB == kLoScale, "cross terms of the (hi, lo) scheme");
 
 __device__ __forceinline__ float vg_pow2_ceil_scale(float mx) {
   if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;          // zero / Inf / NaN: unscaled
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
   //   A1 (16x16x16): k = output 4 g + j, hi                     x  W hi
   //   A2 (16x16x32): k = 8 g + j: (g < 2: lo, g >= 2: hi) of output 8 (g & 1) + j   x  (W hi | W lo) -- lo x hi + hi x lo in ONE MFMA
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  const float sclA = __builtin_ldexpf(1.0f, -kVgExpA);
   h4v* gA1 = reinterpret_cast<h4v*>(p + kVgDist);
   h8_t* gA2 = reinterpret_cast<h8_t*>(p + kVgDist + 1024);
   if (role == 1) {
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
     for (int j = 0; j < 4; ++j) {
       const int o = 4 * g + j;
       float v = 0.0f;
-      if (q < B && o < O) v = gq * gout[q * O + o] * (oscale[o] / sh);
+      if (q < B && o < O) v = gq * gout[q * O + o] * (oscale[o] / sh) * sclA;
       _Float16 h, l;
       split_static_f16(v, h, l);
       hi[j] = h;
@@ -135,10 +143,12 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
       const int o = O <= kVgOC ? (k < 30 ? k % 10 : 16) : 8 * (g & 1) + j;
       const bool want_lo = O <= kVgOC ? (k >= 10 && k < 20) : g < 2;
       float v = 0.0f;
-      if (q < B && o < O) v = gq * gout[q * O + o] * (oscale[o] / sh);
+      if (q < B && o < O) v = gq * gout[q * O + o] * (oscale[o] / sh) * sclA;
       _Float16 h, l;
       split_static_f16(v, h, l);
-      mix[j] = want_lo ? l : h;
+      // O <= kVgOC: the cross terms' 2^-11 is shared between the two sides (2^-5 here, 2^-6 on the weights) so that neither
+      // operand sinks deeper into the f16 subnormals than 2^-17 of its largest entry
+      mix[j] = (O <= kVgOC && k >= 10) ? (_Float16)((float)(want_lo ? l : h) * kVgCrossA) : (want_lo ? l : h);
     }
     gA1[s * 64 + lane] = hi;
     gA2[s * 64 + lane] = mix;
@@ -184,6 +194,22 @@ __device__ __forceinline__ void split_pair_plain(float p0, float p1, unsigned& h
   lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
 }
 
+// The 8 transcendentals of a query half straight from the MFMA result registers into fresh ones (the in-place form costs 8 v_mov
+// copies per half: u is needed again for d log_sigs).  The hazard recogniser does not look into inline asm: the wait states an
+// MFMA result needs before a VALU instruction may read it are the leading s_nop 7.
+template <int BC>
+__device__ __forceinline__ void trans8_from_mfma(const f4_t (&u)[2], float (&o)[8]) {
+#define IRBFN_T8G(OP)                                                                                                              \
+  asm volatile("s_nop 7\n " OP " %0, %8\n " OP " %1, %9\n " OP " %2, %10\n " OP " %3, %11\n " OP " %4, %12\n " OP " %5, %13\n " OP         \
+               " %6, %14\n " OP " %7, %15\n s_nop 0"                                                                                \
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])           \
+               : "v"(u[0][0]), "v"(u[0][1]), "v"(u[0][2]), "v"(u[0][3]), "v"(u[1][0]), "v"(u[1][1]), "v"(u[1][2]), "v"(u[1][3]));
+  if constexpr (BC == BC_GAUSS) { IRBFN_T8G("v_exp_f32_e32") }
+  else if constexpr (BC == BC_IQ) { IRBFN_T8G("v_rcp_f32_e32") }
+  else { IRBFN_T8G("v_rsq_f32_e32") }
+#undef IRBFN_T8G
+}
+
 struct VjpGArgs {
   const unsigned char* __restrict__ qblk;   // [nqb][kVgBlock]
   const float* __restrict__ scales;         // [0] = s_g, [1] = s_h
@@ -225,7 +251,8 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
   constexpr float PS = gram_phi_scale<BC>();                 // the basis value arrives as P = PS phi
   // tt_true = tts * KT:  tts = hb * P^p * 2^-ET (|tts| < 2^15), hb = gamma hbar 2^30 / s_h, dphi/dd2 = const * phi^p
   constexpr int ET = BC == BC_GAUSS ? 33 : (BC == BC_IQ ? 47 : 40);       // 34 + p log2(PS) - 15
-  const float cE = __builtin_ldexpf(1.0f, -ET);
+  const float cE = __builtin_ldexpf(1.0f, -(ET - kVgExpA - kVgExpB));      // what the operand scales leave of 2^-ET (gaussian: 1)
+  static_assert(ET >= kVgExpA + kVgExpB, "operand scales");
   const float KT = sh * (1.0f / (kWScale * kWScale)) * __builtin_ldexpf(1.0f, ET) *
                    (BC == BC_GAUSS ? -a.gscale / PS : (BC == BC_IQ ? -1.0f / (PS * PS) : -0.5f / (PS * PS * PS)));
 
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
   h4_t cbh[2];
   h8_t cbt[2][2];
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  const float sclB = __builtin_ldexpf(1.0f, -kVgExpB);
   h4v wth[2];                                                // B of A1: k = output 4 g + j, W hi
   h8_t wt2[2];                                               // B of A2: k = 8 g + j: (g < 2: W hi, g >= 2: W lo) of output 8 (g & 1) + j
   {
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int o = 4 * g + j;
-        const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] : 0.0f;
+        const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] * sclB : 0.0f;
         _Float16 h, l;
         split_static_f16(w, h, l);
         wth[ct][j] = h;
@@ -257,10 +285,10 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
       for (int j = 0; j < 8; ++j) {
         const int k = 8 * g + j;
         const int o = OC ? (k < 30 ? k % 10 : 16) : 8 * (g & 1) + j;
-        const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] : 0.0f;
+        const float w = o < a.O ? rp[DC + 1 + o] / a.oscale[o] * sclB : 0.0f;
         _Float16 h, l;
         split_static_f16(w, h, l);
-        if (OC) wt2[ct][j] = k < 10 ? h : (_Float16)((float)(k < 20 ? h : l) * kLoScale);    // exact (power of two) down to the subnormals
+        if (OC) wt2[ct][j] = k < 10 ? h : (_Float16)((float)(k < 20 ? h : l) * kVgCrossB);   // exact (power of two) down to the subnormals
         else wt2[ct][j] = g < 2 ? h : l;
       }
     }
@@ -313,14 +341,13 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt0, cbt[ct][0], u[ct], 0, 0, 0);
           u[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qt1, cbt[ct][1], u[ct], 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hb[ct][r] = OC ? hb[ct][r] * cE : __builtin_fmaf(hl[r], kLoScale, hb[ct][r]) * cE;
+          for (int r = 0; r < 4; ++r) {
+            if (!OC) hb[ct][r] = __builtin_fmaf(hl[r], kLoScale, hb[ct][r]);
+            if (ET > kVgExpA + kVgExpB) hb[ct][r] *= cE;
+          }
         }
         float t8[8];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t8[ct * 4 + r] = u[ct][r];
-        trans_block<BC, 8>(t8);                              // P = PS phi
+        trans8_from_mfma<BC>(u, t8);                         // P = PS phi
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
