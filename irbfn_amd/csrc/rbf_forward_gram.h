@@ -241,6 +241,14 @@ __device__ __forceinline__ void gram_heads2(const h4_t& a, const h4_t (&b)[2], f
       : "v"(a), "v"(b[0]), "v"(b[1]));
 }
 
+// ... with a start value c in the accumulator (K2g, gaussian: c = -14 takes the 2^14 of the basis value out again, so that the
+// result IS alpha d^2; a multiple of the head grid and inside the budget that holds the +14 of c2, hence still exact)
+__device__ __forceinline__ void gram_heads2c(const h4_t& a, const h4_t (&b)[2], const f4_t& c, f4_t (&u)[2]) {
+  asm("v_mfma_f32_16x16x16_f16 %0, %2, %3, %5\n v_mfma_f32_16x16x16_f16 %1, %2, %4, %5\n s_nop 4"
+      : "=&v"(u[0]), "=&v"(u[1])
+      : "v"(a), "v"(b[0]), "v"(b[1]), "v"(c));
+}
+
 // the argument of the transcendental for the 2 x 2 tiles (query tile t, centre tile ct) of the chunk image at `buf`: head sum
 // (exact), then the tails
 __device__ __forceinline__ void gram_distances(const unsigned char* buf, int lane, const h4_t (&bhd)[2], const h8_t (&btl)[2][2],

@@ -38,7 +38,9 @@ constexpr int kVgOC = 10;                                // up to this many outp
 // weight side 2^-17 (<= 1/4) on top of the 2^15 of split_static_f16 -- small entries sink into the f16 subnormals, which the
 // matrix cores honour: a (hi, lo) pair then keeps 2^-36 ABSOLUTE against operands of size 2^-2, beyond float32.  The gaussian
 // (ET = 33) needs no multiplication of hbar at all any more, the other bases one by 2^-(ET - 33).
-constexpr int kVgExpA = 16, kVgExpB = 17;
+// (The gaussian's basis value is taken as phi itself here -- see kVgShift in the kernel -- so its factor is 2^-19: 2^-9 and 2^-10.)
+__host__ __device__ constexpr int vg_exp_a(int bc) { return bc == BC_GAUSS ? 9 : 16; }
+__host__ __device__ constexpr int vg_exp_b(int bc) { return bc == BC_GAUSS ? 10 : 17; }
 constexpr float kVgCrossA = 1.0f / 32.0f, kVgCrossB = 1.0f / 64.0f;      // kVgCrossA * kVgCrossB = kLoScale (2^-11)
 static_assert(kVgCrossA * kVgCrossB == kLoScale, "cross terms of the (hi, lo) scheme");
 
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
                                                                   const float* __restrict__ bmax, int nbmax,
                                                                   const float* __restrict__ oscale, const GramHdr* __restrict__ hdr,
                                                                   unsigned char* __restrict__ qblk, float* __restrict__ scales,
-                                                                  int* __restrict__ flag, int gen, GateTables gt, long B, int D, int O) {
+                                                                  int* __restrict__ flag, int gen, GateTables gt, long B, int D, int O, int expA) {
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long q0 = (long)blockIdx.x * 32;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(192) void vjp_pack_blocks_gram_kernel(const float* 
   //   A1 (16x16x16): k = output 4 g + j, hi                     x  W hi
   //   A2 (16x16x32): k = 8 g + j: (g < 2: lo, g >= 2: hi) of output 8 (g & 1) + j   x  (W hi | W lo) -- lo x hi + hi x lo in ONE MFMA
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-  const float sclA = __builtin_ldexpf(1.0f, -kVgExpA);
+  const float sclA = __builtin_ldexpf(1.0f, -expA);
   h4v* gA1 = reinterpret_cast<h4v*>(p + kVgDist);
   h8_t* gA2 = reinterpret_cast<h8_t*>(p + kVgDist + 1024);
   if (role == 1) {
@@ -248,9 +250,14 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
   const bool active = chunk < a.nchunks;
   const int cb = chunk * 32;
   const float sg = a.scales[0], sh = a.scales[1];
-  constexpr float PS = gram_phi_scale<BC>();                 // the basis value arrives as P = PS phi
+  // Gaussian: the head sum starts from -14 (gram_heads2c), so u = alpha d^2 itself and the transcendental returns phi (PS = 1):
+  // no subtraction per pair for d log_sigs.  phi <= 1 as an ungained (hi, lo) pair is good to 2^-25 absolute -- of a gradient's
+  // largest terms, which is what a gradient is judged against.  The other bases keep P = 2^14 phi / 2^7 phi.
+  constexpr bool kVgShift = BC == BC_GAUSS;
+  constexpr float PS = kVgShift ? 1.0f : gram_phi_scale<BC>();                 // the basis value arrives as P = PS phi
   // tt_true = tts * KT:  tts = hb * P^p * 2^-ET (|tts| < 2^15), hb = gamma hbar 2^30 / s_h, dphi/dd2 = const * phi^p
-  constexpr int ET = BC == BC_GAUSS ? 33 : (BC == BC_IQ ? 47 : 40);       // 34 + p log2(PS) - 15
+  constexpr int ET = BC == BC_GAUSS ? 19 : (BC == BC_IQ ? 47 : 40);       // 34 + p log2(PS) - 15
+  constexpr int kVgExpA = vg_exp_a(BC), kVgExpB = vg_exp_b(BC);
   const float cE = __builtin_ldexpf(1.0f, -(ET - kVgExpA - kVgExpB));      // what the operand scales leave of 2^-ET (gaussian: 1)
   static_assert(ET >= kVgExpA + kVgExpB, "operand scales");
   const float KT = sh * (1.0f / (kWScale * kWScale)) * __builtin_ldexpf(1.0f, ET) *
@@ -328,7 +335,8 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
         const h4v gah = *reinterpret_cast<const h4v*>(cur + kVgDist + (s * 64 + lane) * 8);
         const h8_t ga2 = *reinterpret_cast<const h8_t*>(cur + kVgDist + 1024 + (s * 64 + lane) * 16);
         f4_t hb[2], u[2];
-        gram_heads2(qh, cbh, u);                             // exact head sums (rbf_forward_gram.h: why not the builtin)
+        if constexpr (kVgShift) gram_heads2c(qh, cbh, f4_t{-(float)kPhiExp, -(float)kPhiExp, -(float)kPhiExp, -(float)kPhiExp}, u);
+        else gram_heads2(qh, cbh, u);                        // exact head sums (rbf_forward_gram.h: why not the builtin)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           f4_t hl = f4_t{0, 0, 0, 0};
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const Vj
             // alpha d2 (gaussian: u - 14) resp. d2 / sigma^2 (others: 2^14 u - 1) per pair; the centre's own factor at the end.
             // (sum tts u - 14 sum tts with the sum from the dC product's column of ones saves this instruction and costs a factor
             // 14 / <alpha d2> in accuracy: 7e-6 instead of 1e-6 of max |d log_sigs| at config 3 -- measured, not taken)
-            const float v = BC == BC_GAUSS ? u[ct][r] - (float)kPhiExp : __builtin_fmaf(u[ct][r], kPhiScale, -1.0f);
+            const float v = kVgShift ? u[ct][r] : __builtin_fmaf(u[ct][r], kPhiScale, -1.0f);
             gls[ct] = __builtin_fmaf(tts, v, gls[ct]);
             hq[ct][4 * s + r] = P;
             tq[ct][4 * s + r] = tts;
@@ -472,10 +480,10 @@ int launch_vjp_gram(irbfn_net* net, const float* x, const float* gout, int64_t B
   const GramHdr* hdr = reinterpret_cast<const GramHdr*>(net->gram_hdr);
   const dim3 pg((unsigned)nqb), pb(192);
   switch (net->DC) {
-    case 3: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<3>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
-    case 4: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<4>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
-    case 7: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<7>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
-    case 8: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<8>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O); break;
+    case 3: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<3>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O, vg_exp_a(net->bclass)); break;
+    case 4: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<4>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O, vg_exp_a(net->bclass)); break;
+    case 7: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<7>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O, vg_exp_a(net->bclass)); break;
+    case 8: hipLaunchKernelGGL((vjp_pack_blocks_gram_kernel<8>), pg, pb, 0, s, x, gout, bmax, nbmax, net->f16_oscale, hdr, qblk, scales, flag, gen, net->gate(), (long)B, net->D, net->O, vg_exp_a(net->bclass)); break;
     default: return IRBFN_ERR_UNSUPPORTED;
   }
   IRBFN_HIP_CHECK(hipGetLastError());
