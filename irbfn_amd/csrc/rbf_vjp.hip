@@ -416,12 +416,14 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
     off += al((size_t)p.SL * p.V * p.Npad * sizeof(float));
   }
   if (p.use_g) {
-    // K2g: a block = 4 waves = 128 centres; slices so that the launch is ONE resident round (3 waves per SIMD: 768 blocks), at
+    // K2g: a block = 4 waves = 128 centres; slices so that the launch is ONE resident round (3 or 4 waves per SIMD: 768 / 1024 blocks), at
     // least 8 query blocks each (profiles/r03_vjp_qsb_sweep.txt: config 3 198 -> 195 us, the reference's 1000-centre net at
     // B = 80000 107 -> 101 us against 1024 blocks)
     const long nqb = (B + 31) / 32;
     const long gb = ((net->N + 31) / 32 + 3) / 4;
-    long q2 = (768 + gb - 1) / gb;
+    const long resident = net->O <= 10 ? 1024 : 768;       // rbf_vjp_gram.hip: 4 waves per SIMD where hbar is one MFMA (O <= 10), else 3
+    long q2 = (resident + gb - 1) / gb;
+    if (q2 > 64) q2 = 64;                                  // small nets: the slab reduce grows with the slices (N = 1000, B = 80000: 64 slices 84 us, 96: 91)
     if (q2 * 8 > nqb) q2 = (nqb + 7) / 8;
     if (net->opt[IRBFN_OPT_VJP_QSB] > 0) q2 = net->opt[IRBFN_OPT_VJP_QSB];
     if (q2 < 1) q2 = 1;

@@ -229,15 +229,17 @@ struct VjpGArgs {
 };
 
 #ifndef IRBFN_K2G_WAVES
-#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow: 138 VGPRs (O > 10), 129 (O <= 10).  4 (126 VGPRs without a spill
-                                // where hbar is one MFMA) is worth 1.5 % at config 3 with 1024 blocks per launch and spills for O > 10: not taken.
+#define IRBFN_K2G_WAVES 3       // waves per SIMD the register allocation must allow where hbar takes two MFMAs (O > 10): 138 VGPRs
+#endif
+#ifndef IRBFN_K2G_WAVES_OC
+#define IRBFN_K2G_WAVES_OC 4    // O <= 10: fits 128 VGPRs without a spill; config 3: 154 against 158 us (with 1024 blocks per launch, rbf_vjp.hip).
                                 // (Until the head sums went out through gram_heads2 -- rbf_forward_gram.h -- every 4-waves build was WRONG.)
 #endif
 // OC: O <= kVgOC -- hbar's three products (hi x hi, lo x hi, hi x lo over <= 10 outputs: 30 of 32 slots) in ONE 16x16x32 MFMA; the
 // cross terms' B operands carry the 2^-11 of the (hi, lo) scheme, so nothing is left to combine on the VALU (28 instead of 32
 // MFMAs and 16 VALU instructions fewer per 32 x 32 pairs)
 template <int DC, int BC, bool OC>
-__global__ __launch_bounds__(256, IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
+__global__ __launch_bounds__(256, OC ? IRBFN_K2G_WAVES_OC : IRBFN_K2G_WAVES) void rbf_vjp_f16gram(const VjpGArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   if (*a.flag == a.gen) return;
   // (centre block, query slice) in plain grid order: placing the blocks that stream the same query slice on one XCD -- one L2 --
