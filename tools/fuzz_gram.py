@@ -1,5 +1,5 @@
 """Random nets through K1g (forward, against the float64 restatement in numpy below -- tools may not import oracle/) and K2g (parameter
-VJP, against the all-float32 K2): worst errors, non-finite outputs, run-to-run differences.  python tools/fuzz_gram.py [cases] [seed]"""
+VJP, against the all-float32 K2): worst errors, non-finite outputs, run-to-run differences.  python tools/fuzz_gram.py [cases] [seed] [wide]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,9 +25,12 @@ def ref_forward(cfg, P, x):
 def main():
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-    worst_f, worst_v, bad = 0.0, 0.0, []
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    worst_f, worst_v, bad, names = 0.0, 0.0, [], {}
     for case in range(ncase):
         D = int(rng.choice([2, 3, 4, 5, 6, 7, 8])); K = int(rng.choice([17, 32, 50, 100, 129, 200, 333, 512, 1000])); O = int(rng.choice([1, 2, 5, 10, 11, 16]))
+        if wide:                                   # K1g's wide form (16 < O <= 128, d = 7 / 8, >= 256 centres, >= 2048 queries; forward only)
+            D = int(rng.choice([7, 8])); K = int(rng.choice([256, 300, 512, 1000])); O = int(rng.choice([17, 20, 33, 64, 100, 128]))
         basis = str(rng.choice(list(BASES)))
         span = float(rng.choice([0.5, 2.0, 10.0])); off = float(rng.choice([0.0, 3.0, -20.0]))
         lo, hi = np.full(D, off - span), np.full(D, off + span)
@@ -40,7 +43,7 @@ def main():
                         "linear": {"kernel": (rng.normal(size=(K, O)) * 10.0 ** rng.uniform(-3, 2, size=(1, O))).astype(np.float32),
                                    "bias": rng.normal(size=(O,)).astype(np.float32)}}}
         net = WCRBFNet.from_config(cfg)
-        B = int(rng.choice([70, 1500, 2100]))
+        B = int(rng.choice([2048, 2500, 4100])) if wide else int(rng.choice([70, 1500, 2100]))
         x = rng.uniform(lo - 0.1 * span, hi + 0.1 * span, size=(B, D)).astype(np.float32)
         tag = f"case {case}: D={D} K={K} O={O} {basis} span={span} off={off} sig={sig:.2f} B={B}"
         try:
@@ -59,6 +62,9 @@ def main():
         if not np.isfinite(got).all() or not np.array_equal(got, got2) or err > max(3e-6, 3.0 * err1):
             bad.append((tag, "forward", name, f"K1g {err:.2e}", f"K1 {err1:.2e}"))
         worst_f = max(worst_f, err)
+        names[name.split("<")[0]] = names.get(name.split("<")[0], 0) + 1
+        if wide:
+            continue
         xt = torch.from_numpy(x).cuda(); g = torch.from_numpy(rng.normal(size=(B, O)).astype(np.float32)).cuda()
         try:
             net.set_options(vjp_kernel=_lib.VJP_K2G)
@@ -74,6 +80,7 @@ def main():
             if not torch.isfinite(a[grp][nm]).all() or not torch.equal(a[grp][nm], a2[grp][nm]) or e > 2e-5:
                 bad.append((tag, "vjp " + nm, e))
             worst_v = max(worst_v, e)
+    print("forward kernels:", names)
     print(f"{ncase} cases: worst forward error / sum|terms| {worst_f:.2e}; worst VJP error / max|leaf| vs K2 {worst_v:.2e}; flagged: {len(bad)}")
     for b in bad[:20]:
         print("  ", b)
