@@ -402,7 +402,9 @@ static VjpPlan make_plan(const irbfn_net* net, int64_t B) {
   p.CT = net->opt[IRBFN_OPT_VJP_F16_CT] == 4 ? 4 : 2;
   const size_t blkb = vjph_block_bytes(net) > vjpg_block_bytes() ? vjph_block_bytes(net) : vjpg_block_bytes();
   p.off_qblk = off;  off += al(vjph_eligible(net) ? (size_t)((B + 31) / 32) * blkb : 0);
-  p.use_g = p.use_h && vjpg_eligible(net) && (vk == IRBFN_VJP_K2G || (vk == IRBFN_VJP_AUTO && B >= 16384)) && net->opt[IRBFN_OPT_VJP_F16_CT] == 0;
+  // K2g in front of K2h from 8192 queries and 2.5e7 (query, centre) pairs (tools/sweep_vjp_batch.py: 4096 centres: K2g 57.6 vs K2h 64.3 us at
+  // B = 12288, a tie at 8192; 1000 centres: 50.1 vs 52.1 at 24576, 46.3 vs 45.0 at 16384)
+  p.use_g = p.use_h && vjpg_eligible(net) && (vk == IRBFN_VJP_K2G || (vk == IRBFN_VJP_AUTO && B >= 8192 && (long long)B * net->N >= 25000000LL)) && net->opt[IRBFN_OPT_VJP_F16_CT] == 0;
   p.off_misc = off;  off += al((size_t)(p.bias_blocks + 8) * sizeof(float));
   // K2r: several regions with a sparse gate (automatic where the forward takes K1r; IRBFN_VJP_K2R forces it where eligible)
   p.use_sp = sparse_vjp_eligible(net) && (vk == IRBFN_VJP_K2R || (vk == IRBFN_VJP_AUTO && sparse_preferred(net, B)));

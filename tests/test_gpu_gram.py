@@ -545,10 +545,10 @@ def test_training_steps_on_the_matrix_core_kernels_follow_the_float32_ones(gpu):
     steps forced onto K1h + K2h: same losses (1e-5), finite parameters, and the VJP really ran on K2g."""
     import torch
     from irbfn_amd import train
-    card = dict(configs.model_card(3), num_kernels=512)
+    card = dict(configs.model_card(3), num_kernels=2048)            # 16448 x 2048 = 3.4e7 pairs: above K2g's threshold of 2.5e7
     P = configs.synth_params(3)
-    P = {"params": {"rbf_list": {k: v[:, :512] for k, v in P["params"]["rbf_list"].items()},
-                    "linear": {"kernel": P["params"]["linear"]["kernel"][:512], "bias": P["params"]["linear"]["bias"]}}}
+    P = {"params": {"rbf_list": {k: v[:, :2048] for k, v in P["params"]["rbf_list"].items()},
+                    "linear": {"kernel": P["params"]["linear"]["kernel"][:2048], "bias": P["params"]["linear"]["bias"]}}}
     B = 16384 + 64
     x = torch.from_numpy(configs.synth_queries(3, B=B)).cuda()
     y = torch.from_numpy(configs.synth_cotangent(3, B=B)).cuda()
