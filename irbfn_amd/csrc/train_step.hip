@@ -78,12 +78,15 @@ __global__ __launch_bounds__(256) void seeds_oneint_kernel(const float* __restri
 // ---- train_step_fullint ----------------------------------------------------------------------------
 // loss = mean|y_pred[:, [0,T]] - y[:, [0,T]]| + mean|final_pred - final_actual|      (train_nmpc.py:386-390;
 // the middle term |first_pred - first_pred| is identically 0).  O = 2T.
-template <int TMAX>
+// TS: the horizon as a compile-time constant (the reference's T = 5: every label / prediction access a register with a static index
+// instead of a 16-way select chain), 0 = run-time T <= TMAX
+template <int TMAX, int TS = 0>
 __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restrict__ x, const float* __restrict__ yp,
                                                             const float* __restrict__ y, float* __restrict__ gy,
-                                                            float* __restrict__ loss_part, long B, int D, int T,
+                                                            float* __restrict__ loss_part, long B, int D, int Targ,
                                                             float tie) {
   __shared__ float sm[256];
+  const int T = TS ? TS : Targ;
   const int O = 2 * T;
   const float DT = 0.1f, WB = 0.33f, VMAX = 7.0f, VMIN = 0.0f, SMAX = 0.4189f;
   const float inv_y = 1.0f / ((float)B * 2.0f), inv_s = 1.0f / ((float)B * 5.0f);
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
       }
     }
     auto lab = [&](int t, int half) -> float {             // control `t` of the label: a_t (half = 0) / sv_t (half = 1)
-      if constexpr (REGS) {
+      if constexpr (REGS && TS != 0) {
+        return yr[half * TS + t];                          // t and half are loop constants after unrolling
+      } else if constexpr (REGS) {
         float v = 0.0f;
 #pragma unroll
         for (int o = 0; o < 2 * TMAX; ++o) v = (o == half * T + t) ? yr[o] : v;
@@ -113,7 +118,9 @@ __global__ __launch_bounds__(256) void seeds_fullint_kernel(const float* __restr
       }
     };
     auto prd = [&](int t, int half) -> float {
-      if constexpr (REGS) {
+      if constexpr (REGS && TS != 0) {
+        return pr[half * TS + t];
+      } else if constexpr (REGS) {
         float v = 0.0f;
 #pragma unroll
         for (int o = 0; o < 2 * TMAX; ++o) v = (o == half * T + t) ? pr[o] : v;
@@ -337,7 +344,10 @@ int irbfn_train_seeds_fullint(const float* x_dev, const float* y_pred_dev, const
   if (B > 0 && (!x_dev || !y_pred_dev || !y_dev || !gy_dev)) return IRBFN_ERR_BAD_ARG;
   if (!loss_dev || !partials_dev) return IRBFN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (T <= 8)
+  if (T == 5)                                                // the reference's horizon (train_nmpc.py:306-374)
+    hipLaunchKernelGGL((seeds_fullint_kernel<8, 5>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
+                       partials_dev, (long)B, D, T, clip_tie);
+  else if (T <= 8)
     hipLaunchKernelGGL((seeds_fullint_kernel<8>), dim3(seed_blocks(B)), dim3(256), 0, s, x_dev, y_pred_dev, y_dev, gy_dev,
                        partials_dev, (long)B, D, T, clip_tie);
   else
